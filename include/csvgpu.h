@@ -1,0 +1,240 @@
+/*
+ * csvgpu.h — C-ABI of the MI355X (gfx950) hot path of ContextSV.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types,
+ * no exceptions across it. Every entry point names the reference seam
+ * (WGLab/ContextSV, file:line relative to the reference root) it replaces.
+ *
+ * Conventions
+ *   - every call returns CSV_OK (0) or a negative csv_status; nothing throws.
+ *   - the caller owns every buffer; the library owns only the opaque context
+ *     (device workspace, stream, per-kernel timers).
+ *   - one csv_ctx per GPU, used from one host thread at a time.
+ *   - entry points without a suffix take HOST pointers (they stage H2D, run the
+ *     kernels, copy the result back). Entry points ending in `_dev` take DEVICE
+ *     pointers (hipMalloc'd / torch CUDA tensors), run asynchronously on the
+ *     context's stream and are what the benchmark times with inputs resident
+ *     in HBM.
+ *   - there is no CPU fallback anywhere behind this ABI: without a usable HIP
+ *     device csvgpu_create() fails with CSV_ENODEV and nothing else can be called.
+ */
+#ifndef CSVGPU_H
+#define CSVGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSVGPU_ABI_VERSION 1
+
+typedef struct csv_ctx csv_ctx;
+
+typedef enum csv_status {
+    CSV_OK        =  0,
+    CSV_EINVAL    = -1,  /* bad argument (null pointer, eps outside [0,1), min_pts < 1, ...) */
+    CSV_ENODEV    = -2,  /* no usable HIP device / device ordinal out of range */
+    CSV_ENOMEM    = -3,  /* device or host allocation failed */
+    CSV_EHIP      = -4,  /* a HIP runtime call failed; see csvgpu_last_error() */
+    CSV_ECAPACITY = -5   /* caller's output capacity too small; required count is returned */
+} csv_status;
+
+/* ---- alignment records of one shard (normally: one chromosome), struct of arrays ----
+ * Mirrors exactly the fields of htslib's bam1_core_t that the reference reads on this
+ * path (sv_caller.cpp:526,541-545; cnv_caller.cpp:491-502): core.pos (0-based), core.flag,
+ * core.qual, core.tid, core.n_cigar and the packed CIGAR words (len<<4 | op, BAM op codes
+ * M0 I1 D2 N3 S4 H5 P6 =7 X8). Records are in file (coordinate-sorted) order. */
+typedef struct csv_reads {
+    uint64_t        n_reads;
+    uint64_t        n_cigar;    /* total CIGAR words == cigar_off[n_reads] */
+    const int32_t  *pos;        /* [n_reads] 0-based leftmost reference position */
+    const uint16_t *flag;       /* [n_reads] BAM FLAG */
+    const uint8_t  *mapq;       /* [n_reads] MAPQ */
+    const int32_t  *tid;        /* [n_reads] reference id (carried, not interpreted by kernels; may be NULL) */
+    const uint64_t *cigar_off;  /* [n_reads+1] first CIGAR word of each read */
+    const uint32_t *cigar;      /* [n_cigar] packed CIGAR words */
+} csv_reads;
+
+/* One SV signature = one SVCall emitted by SVCaller::processCIGARRecord
+ * (sv_caller.cpp:566-643). 16 bytes, written with a single store on device.
+ *   kind: 0 = CIGARINS (I op), 1 = CIGARDEL (D op), 2 = CIGARCLIP (S op) — the SVDataType
+ *         bit the reference sets (sv_types.h:60-63). SVType is DEL for kind 1, INS otherwise.
+ *   qpos: query offset of the op (reference `query_pos`, sv_caller.cpp:546,653) — the host
+ *         needs it to cut the inserted sequence when op_len == 50 (sv_caller.cpp:589,624). */
+typedef struct csv_sig {
+    uint32_t start;      /* 1-based, = pos+1 (sv_caller.cpp:584,619,636) */
+    uint32_t end;        /* = start + op_len - 1 (sv_caller.cpp:585,620,637) */
+    uint32_t read;       /* index of the emitting read inside the shard */
+    uint32_t qpos_kind;  /* (qpos << 2) | kind */
+} csv_sig;
+#define CSV_SIG_KIND(s) ((s).qpos_kind & 3u)
+#define CSV_SIG_QPOS(s) ((s).qpos_kind >> 2)
+enum { CSV_KIND_INS = 0, CSV_KIND_DEL = 1, CSV_KIND_CLIP = 2 };
+
+/* 6-state PennCNV-style HMM parameters = the fields ReadCHMM fills (khmm.cpp:395-553,
+ * struct CHMM khmm.h:14-32). Row-major A[i*6+j] = P(i -> j). */
+typedef struct csv_hmm {
+    double A[36];
+    double pi[6];
+    double B1_mean[6];
+    double B1_sd[6];
+    double B1_uf;
+    double B2_mean[5];
+    double B2_sd[5];
+    double B2_uf;
+} csv_hmm;
+
+/* Kernel ids for csvgpu_timing_get(). */
+typedef enum csv_kernel_id {
+    CSV_K_CIGAR_SCAN = 0,   /* signature emission + alignment intervals */
+    CSV_K_DEPTH      = 1,   /* tile-owner depth map (+ sum / non-zero count) */
+    CSV_K_SORT       = 2,   /* all radix-sort passes + tie fix-up */
+    CSV_K_DBSCAN     = 3,   /* neighbour count + union + rank + label (interval metric) */
+    CSV_K_DBSCAN1D   = 4,   /* batched 1-D DBSCAN */
+    CSV_K_WINDOW     = 5,   /* window log2 coverage */
+    CSV_K_VITERBI    = 6,   /* emissions + Viterbi DP + backtrack */
+    CSV_K_MISC       = 7,   /* memsets, small scans, partition */
+    CSV_K_COUNT      = 8
+} csv_kernel_id;
+
+/* ------------------------------------------------------------------------------------------ */
+/* context                                                                                      */
+
+/* Create a context on HIP device `device_ordinal`. `stream` may be NULL (the context creates
+ * its own non-blocking stream) or an existing hipStream_t (e.g. torch's current stream) that
+ * every kernel of this context is then launched on. Returns NULL on failure (no device, ...);
+ * csvgpu_last_error(NULL) then describes why. */
+csv_ctx    *csvgpu_create(int device_ordinal, void *stream);
+void        csvgpu_destroy(csv_ctx *ctx);
+int         csvgpu_abi_version(void);
+const char *csvgpu_last_error(const csv_ctx *ctx);
+/* Block until everything queued on the context's stream has finished. */
+int         csvgpu_synchronize(csv_ctx *ctx);
+/* Per-kernel timers: when enabled, each launch group is bracketed by HIP events recorded on
+ * the context's stream; csvgpu_timing_get() synchronises and returns the accumulated device
+ * time and the number of launch groups since the last reset. */
+int         csvgpu_timing_enable(csv_ctx *ctx, int on);
+int         csvgpu_timing_reset(csv_ctx *ctx);
+int         csvgpu_timing_get(csv_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
+
+/* ------------------------------------------------------------------------------------------ */
+/* host-pointer entry points (the seams of SURVEY.md §8b)                                       */
+
+/* Replaces SVCaller::findCIGARSVs + processCIGARRecord + addSVCall for one chromosome
+ * (sv_caller.cpp:506-537, 539-661; sv_object.cpp:22-33).
+ *   filter: flag & (SECONDARY|UNMAP|DUP|QCFAIL|SUPPLEMENTARY) or mapq < min_mapq => skipped (:526).
+ *   depth_len = pos_depth_map.size() (chromosome length + 1); soft clips with pos+1 >= depth_len are
+ *   skipped together with their cursor update (:602-604 `continue`).
+ *   min_oplen = 50 (:566), min_mapq = 20 (sv_caller.h:72) in the reference.
+ * Output order == order of the reference's chr_sv_calls vector after all addSVCall()s: ascending
+ * (start,end); equal (start,end) in REVERSE emission order (std::lower_bound insert, sv_object.cpp:31).
+ * *n_out: in = capacity of `out` in records, out = number of signatures. If the capacity is too
+ * small CSV_ECAPACITY is returned and *n_out holds the required count. */
+int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len,
+                      uint32_t min_oplen, uint8_t min_mapq, csv_sig *out, uint64_t *n_out);
+
+/* Replaces SVCaller::getAlignmentReadPositions (sv_caller.cpp:663-690) and htslib bam_endpos for
+ * every record of the shard (used by findSplitSVSignatures, sv_caller.cpp:152,162):
+ *   q_start = query offset of the first M/I/=/X op (0 if none), q_end = sum of M,I,S,=,X lengths,
+ *   ref_end = pos + reference length of the CIGAR (pos+1 when that length is 0 or the read is unmapped). */
+int csvgpu_aln_intervals(csv_ctx *ctx, const csv_reads *reads,
+                         int32_t *ref_end, int32_t *q_start, int32_t *q_end);
+
+/* Replaces the per-chromosome body of CNVCaller::calculateMeanChromosomeCoverage
+ * (cnv_caller.cpp:488-543): depth[p] (1-based p, depth_len = chr_len+1 entries, entry 0 stays 0)
+ * counts M/=/X bases of every record without UNMAP|SECONDARY|QCFAIL|DUP (no mapq filter,
+ * supplementary included); bases at p >= depth_len are skipped. *sum = sum of depth, *nonzero =
+ * #positions with depth > 0 (mean coverage = sum/nonzero, :534-538). `depth` may be NULL when only
+ * the two scalars are wanted. */
+int csvgpu_depth(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len,
+                 uint32_t *depth, uint64_t *sum, uint32_t *nonzero);
+
+/* Replaces DBSCAN::fit + getClusters (dbscan.cpp:9-81, dbscan.h:13-18): labels[i] for the i-th
+ * interval in CALLER order: -2 noise, 0..k-1 cluster id, identical to the reference's sequential
+ * visit-order labels. Metric = 1 - min reciprocal overlap evaluated in the same IEEE double
+ * expression (dbscan.cpp:74-79). Requires 0 <= eps < 1 and min_pts >= 1 (CSV_EINVAL otherwise). */
+int csvgpu_dbscan_iv(csv_ctx *ctx, const uint32_t *start, const uint32_t *end, uint64_t n,
+                     double eps, int32_t min_pts, int32_t *labels);
+
+/* Replaces DBSCAN1D::fit + getClusters for a batch of independent point sets
+ * (dbscan1d.cpp:8-70; the six fits per overlap group of sv_caller.cpp:270-372 become one call):
+ * segment s = pts[seg_off[s] .. seg_off[s+1]); labels in caller order per segment. Metric
+ * |a-b| (int) <= eps (double). Requires eps >= 0, min_pts >= 1. */
+int csvgpu_dbscan_1d(csv_ctx *ctx, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg,
+                     double eps, int32_t min_pts, int32_t *labels);
+
+/* Replaces the window loop of CNVCaller::querySNPRegion (cnv_caller.cpp:76-113) for a batch of
+ * regions: region r has sample_size[r] windows; window i sums depth[(uint32)(start + i*step + j)]
+ * for integer j < step (step = (end-start+1)/sample_size as double), stops past `end`, skips
+ * positions >= depth_len, and yields log2((sum/count)/mean_cov) (sum==0 -> 1e-9; count==0 -> 0.0).
+ * win_off[r] (n_regions+1 entries) = first output window of region r. Also returns the window
+ * bounds the reference uses as map keys (:80-81). */
+int csvgpu_window_log2(csv_ctx *ctx, const uint32_t *depth, uint32_t depth_len,
+                       const uint32_t *region_start, const uint32_t *region_end,
+                       const int32_t *sample_size, const uint64_t *win_off, uint64_t n_regions,
+                       double mean_cov, double *log2_cov, uint32_t *win_start, uint32_t *win_end);
+
+/* Replaces testVit_CHMM / ViterbiLogNP_CHMM (khmm.cpp:28-56, 225-393) for a batch of observation
+ * sequences: sequence s = observations [seq_off[s], seq_off[s+1]); o2 == -1 means "no BAF".
+ * states[] are 1..6 (the reference's returned vector, dummy 0th element already dropped),
+ * loglik[s] = max final delta. Sequences of length 0 get loglik -1e11 (VITHUGE) and no states. */
+int csvgpu_viterbi(csv_ctx *ctx, const csv_hmm *hmm, const double *o1, const double *o2,
+                   const double *pfb, const uint64_t *seq_off, uint64_t n_seq,
+                   int32_t *states, double *loglik);
+
+/* ------------------------------------------------------------------------------------------ */
+/* device-pointer entry points (inputs resident in HBM; asynchronous on the context's stream)   */
+
+/* Upload a shard once; the returned handle keeps pos/flag/mapq/cigar_off/cigar resident in HBM
+ * together with the per-read side arrays the kernels produce (ref_end, q_start, q_end). */
+typedef struct csv_shard csv_shard;
+csv_shard *csvgpu_shard_upload(csv_ctx *ctx, const csv_reads *host_reads, uint32_t depth_len);
+/* Wrap arrays that already live in HBM (e.g. torch tensors); nothing is copied or owned. */
+csv_shard *csvgpu_shard_wrap_dev(csv_ctx *ctx, const csv_reads *dev_reads, uint32_t depth_len);
+void       csvgpu_shard_free(csv_ctx *ctx, csv_shard *shard);
+
+/* Result of one chromosome's device pipeline; pointers are device memory owned by the shard
+ * and stay valid until the next csvgpu_chr_pipeline_dev() on the same shard or its free. */
+typedef struct csv_chr_result {
+    uint64_t        n_sig;        /* signatures emitted (all kinds) */
+    uint64_t        n_del;        /* of which SVType DEL */
+    uint64_t        n_ins;        /* of which SVType INS (CIGARINS + CIGARCLIP) */
+    uint64_t        depth_sum;
+    uint32_t        depth_nonzero;
+    int32_t         min_pts;      /* ceil(mean_cov * min_pts_pct) or 5 (sv_caller.cpp:723-728) */
+    double          mean_cov;
+    const csv_sig  *sig;          /* [n_sig] in chr_sv_calls order (all kinds interleaved) */
+    const csv_sig  *sig_del;      /* [n_del] the DEL subsequence (std::copy_if order, sv_object.cpp:80) */
+    const csv_sig  *sig_ins;      /* [n_ins] the INS subsequence */
+    const int32_t  *label_del;    /* [n_del] DBSCAN labels of sig_del */
+    const int32_t  *label_ins;    /* [n_ins] DBSCAN labels of sig_ins */
+    const uint32_t *depth;        /* [depth_len] */
+    const int32_t  *ref_end;      /* [n_reads] */
+    const int32_t  *q_start;      /* [n_reads] */
+    const int32_t  *q_end;        /* [n_reads] */
+} csv_chr_result;
+
+/* The whole per-chromosome device path of SVCaller::processChromosome up to cluster labels
+ * (sv_caller.cpp:692-745 with cnv_caller.cpp:488-543 in front): CIGAR scan -> depth map and mean
+ * coverage -> min_pts -> ordering -> per-type interval DBSCAN. Representative selection of
+ * mergeSVs (sv_object.cpp:121-244) is host code above this ABI.
+ * min_pts_pct <= 0 selects the fixed min_pts = 5 (sv_caller.cpp:724-727). */
+int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, uint8_t min_mapq,
+                            double eps, double min_pts_pct, csv_chr_result *result);
+
+/* Device-pointer twins of the clustering / HMM entry points (same semantics as above). */
+int csvgpu_dbscan_iv_dev(csv_ctx *ctx, const uint32_t *d_start, const uint32_t *d_end, uint64_t n,
+                         double eps, int32_t min_pts, int32_t *d_labels);
+int csvgpu_dbscan_1d_dev(csv_ctx *ctx, const int32_t *d_pts, const uint64_t *d_seg_off,
+                         uint64_t n_seg, uint64_t n_pts, uint32_t max_seg_len,
+                         double eps, int32_t min_pts, int32_t *d_labels);
+int csvgpu_viterbi_dev(csv_ctx *ctx, const csv_hmm *hmm, const double *d_o1, const double *d_o2,
+                       const double *d_pfb, const uint64_t *d_seq_off, uint64_t n_seq,
+                       uint64_t n_obs, int32_t *d_states, double *d_loglik);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSVGPU_H */
