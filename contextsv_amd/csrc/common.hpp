@@ -1,0 +1,163 @@
+// common.hpp — internals shared by the gfx950 kernels and the C-ABI glue (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/csvgpu.h"
+
+namespace csv {
+
+constexpr int WAVE = 64;   // gfx950 wavefront
+
+// BAM CIGAR op codes and flags (SAM spec §4.2)
+enum : uint32_t { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_EQ = 7, OP_X = 8 };
+enum : uint32_t { F_UNMAP = 0x4, F_SECONDARY = 0x100, F_QCFAIL = 0x200, F_DUP = 0x400, F_SUPP = 0x800 };
+constexpr uint32_t REF_OPS = (1u << OP_M) | (1u << OP_D) | (1u << OP_N) | (1u << OP_EQ) | (1u << OP_X);   // consume reference
+constexpr uint32_t QRY_OPS = (1u << OP_M) | (1u << OP_I) | (1u << OP_S) | (1u << OP_EQ) | (1u << OP_X);   // consume query
+constexpr uint32_t ALN_OPS = (1u << OP_M) | (1u << OP_EQ) | (1u << OP_X);                                  // count toward depth
+constexpr uint32_t QST_OPS = (1u << OP_M) | (1u << OP_I) | (1u << OP_EQ) | (1u << OP_X);                   // open the query interval
+
+// ---------------------------------------------------------------------------------------------
+// context
+
+struct Timer {
+    hipEvent_t a, b;
+    int id;
+};
+
+struct Arena {                     // grow-only bump allocator over one device buffer; reset per entry point
+    char  *base = nullptr;
+    size_t cap = 0, used = 0;
+};
+
+}  // namespace csv
+
+struct csv_ctx {
+    int          device = 0;
+    hipStream_t  stream = nullptr;
+    bool         own_stream = false;
+    csv::Arena   arena;                     // staged inputs / outputs of the host-pointer entry points
+    csv::Arena   work;                      // workspace sized after the signature count is known
+    void        *pinned = nullptr;          // small pinned host block for scalar read-backs
+    size_t       pinned_cap = 0;
+    bool         timing = false;
+    std::vector<csv::Timer> timers;         // recorded, not yet folded
+    std::vector<hipEvent_t> event_pool;
+    double       t_ms[CSV_K_COUNT] = {0};
+    uint64_t     t_n[CSV_K_COUNT] = {0};
+    std::string  err;
+    int          n_cu = 256;
+};
+
+struct csv_shard {
+    csv_reads d;                   // device pointers
+    uint32_t  depth_len = 0;
+    bool      owned = false;       // true: arrays hipMalloc'd by csvgpu_shard_upload
+    // per-read side arrays + per-chromosome outputs (device, owned by the shard)
+    int32_t  *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr, *pmax_end = nullptr;
+    uint32_t *depth = nullptr;
+    csv_sig  *sig_raw = nullptr;   uint64_t sig_cap = 0;
+    csv_sig  *sig_sorted = nullptr;
+    int32_t  *labels = nullptr;
+    uint32_t *ord = nullptr;       // read permutation by pos when the shard is not coordinate-sorted
+    char     *scratch = nullptr;   size_t scratch_cap = 0;   // sort / dbscan workspace
+    uint64_t *counters = nullptr;  // device scalars (see ScanCounters)
+};
+
+namespace csv {
+
+// device scalars written by the scan / depth kernels, read back once per chromosome
+struct ScanCounters {
+    unsigned long long n_sig;        // all emitted signatures
+    unsigned long long n_del;        // kind == DEL
+    unsigned long long depth_sum;
+    unsigned int       depth_nonzero;
+    unsigned int       max_start;
+    unsigned int       max_len;      // max (end - start) over emitted signatures
+    unsigned int       unsorted;     // != 0 if pos[] is not non-decreasing
+    int                min_pts;      // written by the min_pts kernel
+    int                pad;
+    double             mean_cov;
+};
+
+#define CSV_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return CSV_EHIP;                                                                     \
+        }                                                                                        \
+    } while (0)
+
+int   arena_reserve(csv_ctx *ctx, Arena &a, size_t bytes);       // grow (sync + realloc) if needed, then reset
+void *arena_alloc(Arena &a, size_t bytes);                       // 256-B aligned slice, nullptr if exhausted
+void  timer_begin(csv_ctx *ctx, int id);
+void  timer_end(csv_ctx *ctx);
+int   ensure_pinned(csv_ctx *ctx, size_t bytes);
+
+struct TimerScope {
+    csv_ctx *c;
+    TimerScope(csv_ctx *ctx, int id) : c(ctx) { timer_begin(c, id); }
+    ~TimerScope() { timer_end(c); }
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int bits_of(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
+
+// ---------------------------------------------------------------------------------------------
+// launchers implemented in kernels/*.hip (all asynchronous on `s`)
+
+// scan.hip
+void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
+                       uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
+                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, ScanCounters *cnt);
+// depth.hip
+void launch_prefix_max(hipStream_t s, const int32_t *in, int32_t *out, uint64_t n, void *tmp /* >= 4 KiB + n/1024*4 */);
+size_t prefix_max_tmp_bytes(uint64_t n);
+// ord == nullptr: reads are coordinate-sorted and pos_s == d.pos; otherwise pos_s / pmax_end are in ord order.
+void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *pos_s,
+                        const int32_t *ref_end, const int32_t *pmax_end, uint32_t depth_len, uint32_t *depth,
+                        ScanCounters *cnt);
+void launch_min_pts(hipStream_t s, ScanCounters *cnt, double min_pts_pct);
+// sort.hip
+size_t radix_sort_tmp_bytes(uint64_t n);
+// stable LSD sort of (key,val) pairs by key bits [0,key_bits). Both buffer pairs are clobbered; returns 1 when the
+// result is in keys_out/vals_out, 0 when it is in keys_in/vals_in (even number of passes).
+int  launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_out, uint32_t *vals_out,
+                           uint64_t n, int key_bits, void *tmp);
+void launch_sig_make_keys(hipStream_t s, const csv_sig *sig, uint64_t n, int len_bits, int type_bit_pos,
+                          uint64_t *keys, uint32_t *vals);
+void launch_sig_fix_ties_gather(hipStream_t s, const csv_sig *sig_raw, const uint64_t *keys, const uint32_t *vals,
+                                uint64_t n, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out);
+void launch_iota_keys_u32(hipStream_t s, const uint32_t *k32, uint64_t n, uint64_t *keys, uint32_t *vals);
+void launch_iota_keys_i32(hipStream_t s, const int32_t *k32, uint64_t n, uint64_t *keys, uint32_t *vals);   // order-preserving bias
+void launch_check_sorted_u32(hipStream_t s, const uint32_t *k, uint64_t n, unsigned int *flag);
+void launch_gather_u32(hipStream_t s, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst);
+void launch_exclusive_sum_u32(hipStream_t s, uint32_t *data, uint64_t n, void *tmp);   // in place
+size_t exclusive_sum_tmp_bytes(uint64_t n);
+// dbscan.hip
+size_t dbscan_tmp_bytes(uint64_t n);
+// s,e sorted by start; oid = original index of each sorted position (nullptr: identity).
+// min_pts read from *d_min_pts when d_min_pts != nullptr, else the immediate.
+void launch_dbscan_iv_sorted(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint32_t *oid,
+                             uint64_t n, double eps, int min_pts, const int *d_min_pts, int32_t *labels, void *tmp);
+// dbscan1d.hip
+void launch_dbscan_1d_batched(hipStream_t s, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg,
+                              double eps, int min_pts, int32_t *labels, unsigned int *too_large_flag);
+constexpr uint32_t DBSCAN1D_MAX_SEG = 512;   // larger segments take the generic sorted path
+size_t dbscan1d_big_tmp_bytes(uint64_t n);
+// pts_sorted ascending (int order); oid = original index per sorted position
+void launch_dbscan_1d_big(hipStream_t s, const int32_t *pts_sorted, const uint32_t *oid, uint64_t n, double eps,
+                          int min_pts, int32_t *labels, void *tmp);
+// hmm.hip
+void launch_window_log2(hipStream_t s, const uint32_t *depth, uint32_t depth_len, const uint32_t *rs, const uint32_t *re,
+                        const int32_t *ss, const uint64_t *win_off, uint64_t n_regions, uint64_t n_windows,
+                        double mean_cov, double *log2_cov, uint32_t *ws, uint32_t *we);
+size_t viterbi_tmp_bytes(uint64_t n_obs, uint64_t n_seq);
+void launch_viterbi(hipStream_t s, const csv_hmm &hmm, const double *o1, const double *o2, const double *pfb,
+                    const uint64_t *seq_off, uint64_t n_seq, uint64_t n_obs, int32_t *states, double *loglik, void *tmp);
+
+}  // namespace csv

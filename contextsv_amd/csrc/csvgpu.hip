@@ -1,0 +1,773 @@
+// csvgpu.hip — implementation of the C-ABI in include/csvgpu.h: context, staging, kernel chains.
+// No CPU fallback lives here: every result is produced by the kernels under kernels/.
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "common.hpp"
+
+namespace csv {
+
+static std::string g_create_err;
+
+int arena_reserve(csv_ctx *ctx, Arena &a, size_t bytes)
+{
+    bytes = align_up(bytes + 4096, 4096);
+    if (bytes > a.cap) {
+        CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (a.base) CSV_HIP(ctx, hipFree(a.base));
+        a.base = nullptr; a.cap = 0;
+        size_t want = bytes + bytes / 4;
+        if (hipMalloc((void **)&a.base, want) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipMalloc((void **)&a.base, bytes) != hipSuccess) { (void)hipGetLastError(); a.base = nullptr; ctx->err = "hipMalloc failed (arena)"; return CSV_ENOMEM; }
+            want = bytes;
+        }
+        a.cap = want;
+    }
+    a.used = 0;
+    return CSV_OK;
+}
+
+void *arena_alloc(Arena &a, size_t bytes)
+{
+    const size_t off = align_up(a.used, 256);
+    if (off + bytes > a.cap) return nullptr;
+    a.used = off + bytes;
+    return a.base + off;
+}
+
+int ensure_pinned(csv_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pinned_cap) return CSV_OK;
+    if (ctx->pinned) CSV_HIP(ctx, hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr; ctx->pinned_cap = 0;
+    CSV_HIP(ctx, hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_cap = bytes;
+    return CSV_OK;
+}
+
+static hipEvent_t get_event(csv_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void timer_begin(csv_ctx *ctx, int id)
+{
+    if (!ctx->timing) return;
+    Timer t; t.id = id; t.a = get_event(ctx); t.b = get_event(ctx);
+    (void)hipEventRecord(t.a, ctx->stream);
+    ctx->timers.push_back(t);
+}
+
+void timer_end(csv_ctx *ctx)
+{
+    if (!ctx->timing || ctx->timers.empty()) return;
+    (void)hipEventRecord(ctx->timers.back().b, ctx->stream);
+}
+
+static void fold_timers(csv_ctx *ctx)
+{
+    for (Timer &t : ctx->timers) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            ctx->t_ms[t.id] += ms; ctx->t_n[t.id]++;
+        }
+        ctx->event_pool.push_back(t.a); ctx->event_pool.push_back(t.b);
+    }
+    ctx->timers.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-side chains shared by the host- and device-pointer entry points
+
+struct DevReads {
+    csv_reads d;
+    int32_t *ref_end, *q_start, *q_end;
+    ScanCounters *cnt;
+};
+
+static size_t reads_bytes(const csv_reads *r)
+{
+    const uint64_t n = r->n_reads, m = r->n_cigar;
+    return align_up(n * 4, 256) + align_up(n * 2, 256) + align_up(n, 256) + align_up((n + 1) * 8, 256) + align_up(m * 4 + 16, 256) +
+           3 * align_up(n * 4, 256) + 256;
+}
+
+// copy a host shard into the arena; returns device views
+static int stage_reads(csv_ctx *ctx, const csv_reads *r, DevReads &o)
+{
+    Arena &a = ctx->arena;
+    const uint64_t n = r->n_reads, m = r->n_cigar;
+    int32_t *pos = (int32_t *)arena_alloc(a, n * 4);
+    uint16_t *flag = (uint16_t *)arena_alloc(a, n * 2);
+    uint8_t *mapq = (uint8_t *)arena_alloc(a, n);
+    uint64_t *coff = (uint64_t *)arena_alloc(a, (n + 1) * 8);
+    uint32_t *cig = (uint32_t *)arena_alloc(a, m * 4 + 16);
+    o.ref_end = (int32_t *)arena_alloc(a, n * 4);
+    o.q_start = (int32_t *)arena_alloc(a, n * 4);
+    o.q_end = (int32_t *)arena_alloc(a, n * 4);
+    o.cnt = (ScanCounters *)arena_alloc(a, sizeof(ScanCounters));
+    if (!pos || !flag || !mapq || !coff || !cig || !o.ref_end || !o.q_start || !o.q_end || !o.cnt) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    hipStream_t s = ctx->stream;
+    if (n) {
+        CSV_HIP(ctx, hipMemcpyAsync(pos, r->pos, n * 4, hipMemcpyHostToDevice, s));
+        CSV_HIP(ctx, hipMemcpyAsync(flag, r->flag, n * 2, hipMemcpyHostToDevice, s));
+        CSV_HIP(ctx, hipMemcpyAsync(mapq, r->mapq, n, hipMemcpyHostToDevice, s));
+    }
+    CSV_HIP(ctx, hipMemcpyAsync(coff, r->cigar_off, (n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (m) CSV_HIP(ctx, hipMemcpyAsync(cig, r->cigar, m * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemsetAsync(o.cnt, 0, sizeof(ScanCounters), s));
+    o.d = *r;
+    o.d.pos = pos; o.d.flag = flag; o.d.mapq = mapq; o.d.tid = nullptr; o.d.cigar_off = coff; o.d.cigar = cig;
+    return CSV_OK;
+}
+
+static int check_reads(csv_ctx *ctx, const csv_reads *r)
+{
+    if (!ctx) return CSV_EINVAL;
+    if (!r || !r->cigar_off || (r->n_reads && (!r->pos || !r->flag || !r->mapq)) || (r->n_cigar && !r->cigar)) {
+        ctx->err = "csv_reads: null array"; return CSV_EINVAL;
+    }
+    if (r->n_reads >= 0xffffffffull) { ctx->err = "csv_reads: more than 2^32-2 reads in one shard"; return CSV_EINVAL; }
+    return CSV_OK;
+}
+
+static int read_counters(csv_ctx *ctx, const ScanCounters *d_cnt, ScanCounters &h)
+{
+    int rc = ensure_pinned(ctx, 4096);
+    if (rc) return rc;
+    CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(&h, ctx->pinned, sizeof(ScanCounters));
+    return CSV_OK;
+}
+
+// ordering workspace for n signatures
+struct SortWs {
+    uint64_t *k0, *k1;
+    uint32_t *v0, *v1;
+    void *tmp;
+};
+static size_t sortws_bytes(uint64_t n) { return 2 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + radix_sort_tmp_bytes(n) + 256; }
+static bool sortws_carve(Arena &a, uint64_t n, SortWs &w)
+{
+    w.k0 = (uint64_t *)arena_alloc(a, n * 8); w.k1 = (uint64_t *)arena_alloc(a, n * 8);
+    w.v0 = (uint32_t *)arena_alloc(a, n * 4); w.v1 = (uint32_t *)arena_alloc(a, n * 4);
+    w.tmp = arena_alloc(a, radix_sort_tmp_bytes(n));
+    return w.k0 && w.k1 && w.v0 && w.v1 && w.tmp;
+}
+
+// sig_raw[0..n) (arbitrary order) -> sig_sorted in the reference's vector order; optional SoA start/end.
+// with_type: DEL calls first, then INS calls (per-type subsequences of the vector).
+static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, uint32_t max_start, uint32_t max_len,
+                             bool with_type, SortWs &w, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out)
+{
+    if (!n) return;
+    TimerScope ts(ctx, CSV_K_SORT);
+    const int len_bits = std::max(1, bits_of(max_len));
+    const int start_bits = std::max(1, bits_of(max_start));
+    const int type_pos = with_type ? len_bits + start_bits : -1;
+    const int key_bits = len_bits + start_bits + (with_type ? 1 : 0);
+    launch_sig_make_keys(ctx->stream, sig_raw, n, len_bits, type_pos, w.k0, w.v0);
+    const int in_out = launch_radix_sort_u64(ctx->stream, w.k0, w.v0, w.k1, w.v1, n, key_bits, w.tmp);
+    launch_sig_fix_ties_gather(ctx->stream, sig_raw, in_out ? w.k1 : w.k0, in_out ? w.v1 : w.v0, n, sig_sorted, start_out, end_out);
+}
+
+// depth chain on device arrays. pmax / ord scratch comes from `a`.
+static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t *ref_end, bool unsorted, uint32_t depth_len,
+                       uint32_t *depth, ScanCounters *cnt)
+{
+    const uint64_t n = d.n_reads;
+    TimerScope ts(ctx, CSV_K_DEPTH);
+    if (n == 0 || depth_len == 0) {
+        if (depth && depth_len) CSV_HIP(ctx, hipMemsetAsync(depth, 0, (size_t)depth_len * 4, ctx->stream));
+        return CSV_OK;
+    }
+    int32_t *pmax = (int32_t *)arena_alloc(a, n * 4);
+    void *ptmp = arena_alloc(a, prefix_max_tmp_bytes(n));
+    if (!pmax || !ptmp) { ctx->err = "arena exhausted (depth)"; return CSV_ENOMEM; }
+    const uint32_t *ord = nullptr;
+    const int32_t *pos_s = d.pos;
+    const int32_t *end_s = ref_end;
+    if (unsorted) {
+        // shard not coordinate-sorted: sort the read indices by pos on device and feed the tile search through `ord`
+        SortWs w;
+        uint32_t *pos_g = (uint32_t *)arena_alloc(a, n * 4), *end_g = (uint32_t *)arena_alloc(a, n * 4);
+        if (!sortws_carve(a, n, w) || !pos_g || !end_g) { ctx->err = "arena exhausted (depth/unsorted)"; return CSV_ENOMEM; }
+        launch_iota_keys_i32(ctx->stream, d.pos, n, w.k0, w.v0);
+        const int io = launch_radix_sort_u64(ctx->stream, w.k0, w.v0, w.k1, w.v1, n, 32, w.tmp);
+        const uint32_t *perm = io ? w.v1 : w.v0;
+        launch_gather_u32(ctx->stream, (const uint32_t *)d.pos, perm, n, pos_g);
+        launch_gather_u32(ctx->stream, (const uint32_t *)ref_end, perm, n, end_g);
+        ord = perm; pos_s = (const int32_t *)pos_g; end_s = (const int32_t *)end_g;
+    }
+    launch_prefix_max(ctx->stream, end_s, pmax, n, ptmp);
+    launch_depth_tiles(ctx->stream, d, ord, pos_s, ref_end, pmax, depth_len, depth, cnt);
+    return CSV_OK;
+}
+static size_t depth_chain_bytes(uint64_t n)
+{
+    return align_up(n * 4, 256) + prefix_max_tmp_bytes(n) + sortws_bytes(n) + 2 * align_up(n * 4, 256) + 1024;
+}
+
+// interval DBSCAN on device arrays in caller order
+static int dbscan_iv_chain(csv_ctx *ctx, Arena &a, const uint32_t *d_start, const uint32_t *d_end, uint64_t n, double eps,
+                           int min_pts, int32_t *d_labels)
+{
+    if (n == 0) return CSV_OK;
+    unsigned int *flag = (unsigned int *)arena_alloc(a, 256);
+    void *tmp = arena_alloc(a, dbscan_tmp_bytes(n));
+    if (!flag || !tmp) { ctx->err = "arena exhausted (dbscan)"; return CSV_ENOMEM; }
+    CSV_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    launch_check_sorted_u32(ctx->stream, d_start, n, flag);
+    int rc = ensure_pinned(ctx, 4096);
+    if (rc) return rc;
+    CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool unsorted = *(unsigned int *)ctx->pinned != 0;
+    if (!unsorted) {
+        TimerScope ts(ctx, CSV_K_DBSCAN);
+        launch_dbscan_iv_sorted(ctx->stream, d_start, d_end, nullptr, n, eps, min_pts, nullptr, d_labels, tmp);
+        return CSV_OK;
+    }
+    SortWs w;
+    uint32_t *s_s = (uint32_t *)arena_alloc(a, n * 4), *e_s = (uint32_t *)arena_alloc(a, n * 4);
+    if (!sortws_carve(a, n, w) || !s_s || !e_s) { ctx->err = "arena exhausted (dbscan sort)"; return CSV_ENOMEM; }
+    const uint32_t *perm;
+    {
+        TimerScope ts(ctx, CSV_K_SORT);
+        launch_iota_keys_u32(ctx->stream, d_start, n, w.k0, w.v0);
+        const int io = launch_radix_sort_u64(ctx->stream, w.k0, w.v0, w.k1, w.v1, n, 32, w.tmp);
+        perm = io ? w.v1 : w.v0;
+        launch_gather_u32(ctx->stream, d_start, perm, n, s_s);
+        launch_gather_u32(ctx->stream, d_end, perm, n, e_s);
+    }
+    TimerScope ts(ctx, CSV_K_DBSCAN);
+    launch_dbscan_iv_sorted(ctx->stream, s_s, e_s, perm, n, eps, min_pts, nullptr, d_labels, tmp);
+    return CSV_OK;
+}
+static size_t dbscan_iv_chain_bytes(uint64_t n) { return 512 + dbscan_tmp_bytes(n) + sortws_bytes(n) + 2 * align_up(n * 4, 256) + 1024; }
+
+}  // namespace csv
+
+using namespace csv;
+
+// =============================================================================================
+extern "C" {
+
+int csvgpu_abi_version(void) { return CSVGPU_ABI_VERSION; }
+
+const char *csvgpu_last_error(const csv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+csv_ctx *csvgpu_create(int device_ordinal, void *stream)
+{
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        (void)hipGetLastError();
+        g_create_err = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return nullptr;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n_dev) { g_create_err = "device ordinal out of range"; return nullptr; }
+    if (hipSetDevice(device_ordinal) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
+    csv_ctx *ctx = new (std::nothrow) csv_ctx();
+    if (!ctx) { g_create_err = "out of host memory"; return nullptr; }
+    ctx->device = device_ordinal;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete ctx; return nullptr; }
+        ctx->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return ctx;
+}
+
+void csvgpu_destroy(csv_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    fold_timers(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    if (ctx->work.base) (void)hipFree(ctx->work.base);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int csvgpu_synchronize(csv_ctx *ctx)
+{
+    if (!ctx) return CSV_EINVAL;
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
+int csvgpu_timing_enable(csv_ctx *ctx, int on) { if (!ctx) return CSV_EINVAL; ctx->timing = on != 0; return CSV_OK; }
+
+int csvgpu_timing_reset(csv_ctx *ctx)
+{
+    if (!ctx) return CSV_EINVAL;
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    fold_timers(ctx);
+    for (int i = 0; i < CSV_K_COUNT; i++) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
+    return CSV_OK;
+}
+
+int csvgpu_timing_get(csv_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches)
+{
+    if (!ctx || kernel_id < 0 || kernel_id >= CSV_K_COUNT) return CSV_EINVAL;
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    fold_timers(ctx);
+    if (total_ms) *total_ms = ctx->t_ms[kernel_id];
+    if (launches) *launches = ctx->t_n[kernel_id];
+    return CSV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, uint32_t min_oplen, uint8_t min_mapq,
+                      csv_sig *out, uint64_t *n_out)
+{
+    int rc = check_reads(ctx, reads);
+    if (rc) return rc;
+    if (!n_out || (*n_out && !out)) { ctx->err = "cigar_scan: null output"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    const uint64_t cap = std::min<uint64_t>(*n_out, reads->n_cigar);
+    rc = arena_reserve(ctx, ctx->arena, reads_bytes(reads) + align_up(cap * sizeof(csv_sig), 256) + 1024);
+    if (rc) return rc;
+    DevReads dr;
+    if ((rc = stage_reads(ctx, reads, dr))) return rc;
+    csv_sig *sig_raw = (csv_sig *)arena_alloc(ctx->arena, cap * sizeof(csv_sig) + 16);
+    if (!sig_raw) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    {
+        TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, min_oplen, min_mapq, 1, sig_raw, cap, dr.ref_end, dr.q_start, dr.q_end, dr.cnt);
+    }
+    ScanCounters h;
+    if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
+    const uint64_t n = h.n_sig;
+    *n_out = n;
+    if (n > cap) { ctx->err = "cigar_scan: output capacity too small"; return CSV_ECAPACITY; }
+    if (n == 0) return CSV_OK;
+    if ((rc = arena_reserve(ctx, ctx->work, sortws_bytes(n) + align_up(n * sizeof(csv_sig), 256) + 1024))) return rc;
+    SortWs w;
+    csv_sig *sig_sorted = (csv_sig *)arena_alloc(ctx->work, n * sizeof(csv_sig));
+    if (!sortws_carve(ctx->work, n, w) || !sig_sorted) { ctx->err = "arena exhausted (sort)"; return CSV_ENOMEM; }
+    order_signatures(ctx, sig_raw, n, h.max_start, h.max_len, false, w, sig_sorted, nullptr, nullptr);
+    CSV_HIP(ctx, hipMemcpyAsync(out, sig_sorted, n * sizeof(csv_sig), hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
+int csvgpu_aln_intervals(csv_ctx *ctx, const csv_reads *reads, int32_t *ref_end, int32_t *q_start, int32_t *q_end)
+{
+    int rc = check_reads(ctx, reads);
+    if (rc) return rc;
+    if (reads->n_reads && (!ref_end || !q_start || !q_end)) { ctx->err = "aln_intervals: null output"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    if ((rc = arena_reserve(ctx, ctx->arena, reads_bytes(reads) + 1024))) return rc;
+    DevReads dr;
+    if ((rc = stage_reads(ctx, reads, dr))) return rc;
+    {
+        TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, 0, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.cnt);
+    }
+    const uint64_t n = reads->n_reads;
+    if (n) {
+        CSV_HIP(ctx, hipMemcpyAsync(ref_end, dr.ref_end, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CSV_HIP(ctx, hipMemcpyAsync(q_start, dr.q_start, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CSV_HIP(ctx, hipMemcpyAsync(q_end, dr.q_end, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
+int csvgpu_depth(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, uint32_t *depth, uint64_t *sum, uint32_t *nonzero)
+{
+    int rc = check_reads(ctx, reads);
+    if (rc) return rc;
+    (void)hipSetDevice(ctx->device);
+    if ((rc = arena_reserve(ctx, ctx->arena, reads_bytes(reads) + align_up((size_t)depth_len * 4 + 16, 256) + 1024))) return rc;
+    DevReads dr;
+    if ((rc = stage_reads(ctx, reads, dr))) return rc;
+    uint32_t *d_depth = (uint32_t *)arena_alloc(ctx->arena, (size_t)depth_len * 4 + 16);
+    if (!d_depth) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    {
+        TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.cnt);
+    }
+    ScanCounters h;
+    if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(reads->n_reads)))) return rc;
+    if ((rc = depth_chain(ctx, ctx->work, dr.d, dr.ref_end, h.unsorted != 0, depth_len, d_depth, dr.cnt))) return rc;
+    if (depth && depth_len) CSV_HIP(ctx, hipMemcpyAsync(depth, d_depth, (size_t)depth_len * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
+    if (sum) *sum = h.depth_sum;
+    if (nonzero) *nonzero = h.depth_nonzero;
+    return CSV_OK;
+}
+
+static int check_dbscan_args(csv_ctx *ctx, double eps, int32_t min_pts, bool interval)
+{
+    if (!ctx) return CSV_EINVAL;
+    if (!(eps >= 0.0) || (interval && !(eps < 1.0))) { ctx->err = interval ? "dbscan: eps must be in [0,1)" : "dbscan1d: eps must be >= 0"; return CSV_EINVAL; }
+    if (min_pts < 1) { ctx->err = "dbscan: min_pts must be >= 1"; return CSV_EINVAL; }
+    return CSV_OK;
+}
+
+int csvgpu_dbscan_iv_dev(csv_ctx *ctx, const uint32_t *d_start, const uint32_t *d_end, uint64_t n, double eps,
+                         int32_t min_pts, int32_t *d_labels)
+{
+    int rc = check_dbscan_args(ctx, eps, min_pts, true);
+    if (rc) return rc;
+    if (n && (!d_start || !d_end || !d_labels)) { ctx->err = "dbscan: null array"; return CSV_EINVAL; }
+    if (n >= 0xffffffffull) { ctx->err = "dbscan: n too large"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    if ((rc = arena_reserve(ctx, ctx->work, dbscan_iv_chain_bytes(n)))) return rc;
+    return dbscan_iv_chain(ctx, ctx->work, d_start, d_end, n, eps, min_pts, d_labels);
+}
+
+int csvgpu_dbscan_iv(csv_ctx *ctx, const uint32_t *start, const uint32_t *end, uint64_t n, double eps, int32_t min_pts,
+                     int32_t *labels)
+{
+    int rc = check_dbscan_args(ctx, eps, min_pts, true);
+    if (rc) return rc;
+    if (n == 0) return CSV_OK;
+    if (!start || !end || !labels) { ctx->err = "dbscan: null array"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    if ((rc = arena_reserve(ctx, ctx->arena, 3 * align_up(n * 4, 256) + 1024))) return rc;
+    uint32_t *ds = (uint32_t *)arena_alloc(ctx->arena, n * 4), *de = (uint32_t *)arena_alloc(ctx->arena, n * 4);
+    int32_t *dl = (int32_t *)arena_alloc(ctx->arena, n * 4);
+    if (!ds || !de || !dl) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    CSV_HIP(ctx, hipMemcpyAsync(ds, start, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    CSV_HIP(ctx, hipMemcpyAsync(de, end, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = csvgpu_dbscan_iv_dev(ctx, ds, de, n, eps, min_pts, dl))) return rc;
+    CSV_HIP(ctx, hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
+int csvgpu_dbscan_1d_dev(csv_ctx *ctx, const int32_t *d_pts, const uint64_t *d_seg_off, uint64_t n_seg, uint64_t n_pts,
+                         uint32_t max_seg_len, double eps, int32_t min_pts, int32_t *d_labels)
+{
+    int rc = check_dbscan_args(ctx, eps, min_pts, false);
+    if (rc) return rc;
+    if (n_seg == 0) return CSV_OK;
+    if (!d_seg_off || (n_pts && (!d_pts || !d_labels))) { ctx->err = "dbscan1d: null array"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    const bool has_big = max_seg_len > DBSCAN1D_MAX_SEG;
+    size_t need = 1024 + (has_big ? (n_seg + 1) * 8 + dbscan1d_big_tmp_bytes(max_seg_len) + sortws_bytes(max_seg_len) + align_up((size_t)max_seg_len * 4, 256) : 0);
+    if ((rc = arena_reserve(ctx, ctx->work, need))) return rc;
+    unsigned int *flag = (unsigned int *)arena_alloc(ctx->work, 256);
+    CSV_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    {
+        TimerScope ts(ctx, CSV_K_DBSCAN1D);
+        launch_dbscan_1d_batched(ctx->stream, d_pts, d_seg_off, n_seg, eps, min_pts, d_labels, flag);
+    }
+    if (!has_big) return CSV_OK;
+    // segments longer than the LDS kernel's limit: generic sorted-window path, one segment at a time
+    std::vector<uint64_t> off(n_seg + 1);
+    CSV_HIP(ctx, hipMemcpyAsync(off.data(), d_seg_off, (n_seg + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SortWs w;
+    uint32_t *ks = (uint32_t *)arena_alloc(ctx->work, (size_t)max_seg_len * 4);
+    void *tmp = arena_alloc(ctx->work, dbscan1d_big_tmp_bytes(max_seg_len));
+    if (!sortws_carve(ctx->work, max_seg_len, w) || !ks || !tmp) { ctx->err = "arena exhausted (dbscan1d big)"; return CSV_ENOMEM; }
+    for (uint64_t s = 0; s < n_seg; s++) {
+        const uint64_t n = off[s + 1] - off[s];
+        if (n <= DBSCAN1D_MAX_SEG) continue;
+        if (n > max_seg_len) { ctx->err = "dbscan1d: max_seg_len smaller than a segment"; return CSV_EINVAL; }
+        TimerScope ts(ctx, CSV_K_DBSCAN1D);
+        launch_iota_keys_i32(ctx->stream, d_pts + off[s], n, w.k0, w.v0);
+        const int io = launch_radix_sort_u64(ctx->stream, w.k0, w.v0, w.k1, w.v1, n, 32, w.tmp);
+        const uint32_t *perm = io ? w.v1 : w.v0;
+        launch_gather_u32(ctx->stream, (const uint32_t *)(d_pts + off[s]), perm, n, ks);   // points in sorted order
+        launch_dbscan_1d_big(ctx->stream, (const int32_t *)ks, perm, n, eps, min_pts, d_labels + off[s], tmp);
+    }
+    return CSV_OK;
+}
+
+int csvgpu_dbscan_1d(csv_ctx *ctx, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg, double eps, int32_t min_pts,
+                     int32_t *labels)
+{
+    int rc = check_dbscan_args(ctx, eps, min_pts, false);
+    if (rc) return rc;
+    if (n_seg == 0) return CSV_OK;
+    if (!seg_off) { ctx->err = "dbscan1d: null seg_off"; return CSV_EINVAL; }
+    const uint64_t n = seg_off[n_seg];
+    uint64_t max_len = 0;
+    for (uint64_t s = 0; s < n_seg; s++) {
+        if (seg_off[s + 1] < seg_off[s]) { ctx->err = "dbscan1d: seg_off not monotone"; return CSV_EINVAL; }
+        max_len = std::max(max_len, seg_off[s + 1] - seg_off[s]);
+    }
+    if (n == 0) return CSV_OK;
+    if (!pts || !labels) { ctx->err = "dbscan1d: null array"; return CSV_EINVAL; }
+    if (max_len >= 0xffffffffull) { ctx->err = "dbscan1d: segment too large"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    if ((rc = arena_reserve(ctx, ctx->arena, 2 * align_up(n * 4, 256) + align_up((n_seg + 1) * 8, 256) + 1024))) return rc;
+    int32_t *dp = (int32_t *)arena_alloc(ctx->arena, n * 4), *dl = (int32_t *)arena_alloc(ctx->arena, n * 4);
+    uint64_t *doff = (uint64_t *)arena_alloc(ctx->arena, (n_seg + 1) * 8);
+    if (!dp || !dl || !doff) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    CSV_HIP(ctx, hipMemcpyAsync(dp, pts, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    CSV_HIP(ctx, hipMemcpyAsync(doff, seg_off, (n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = csvgpu_dbscan_1d_dev(ctx, dp, doff, n_seg, n, (uint32_t)max_len, eps, min_pts, dl))) return rc;
+    CSV_HIP(ctx, hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
+int csvgpu_window_log2_dev(csv_ctx *ctx, const uint32_t *d_depth, uint32_t depth_len, const uint32_t *d_rs, const uint32_t *d_re,
+                           const int32_t *d_ss, const uint64_t *d_win_off, uint64_t n_regions, uint64_t n_windows,
+                           double mean_cov, double *d_log2, uint32_t *d_ws, uint32_t *d_we)
+{
+    if (!ctx) return CSV_EINVAL;
+    if (n_regions == 0 || n_windows == 0) return CSV_OK;
+    if (!d_depth || !d_rs || !d_re || !d_ss || !d_win_off || !d_log2 || !d_ws || !d_we) { ctx->err = "window_log2: null array"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    TimerScope ts(ctx, CSV_K_WINDOW);
+    launch_window_log2(ctx->stream, d_depth, depth_len, d_rs, d_re, d_ss, d_win_off, n_regions, n_windows, mean_cov, d_log2, d_ws, d_we);
+    return CSV_OK;
+}
+
+int csvgpu_window_log2(csv_ctx *ctx, const uint32_t *depth, uint32_t depth_len, const uint32_t *region_start,
+                       const uint32_t *region_end, const int32_t *sample_size, const uint64_t *win_off, uint64_t n_regions,
+                       double mean_cov, double *log2_cov, uint32_t *win_start, uint32_t *win_end)
+{
+    if (!ctx) return CSV_EINVAL;
+    if (n_regions == 0) return CSV_OK;
+    if (!depth || !region_start || !region_end || !sample_size || !win_off) { ctx->err = "window_log2: null array"; return CSV_EINVAL; }
+    for (uint64_t r = 0; r < n_regions; r++) {
+        if (sample_size[r] <= 0 || win_off[r + 1] - win_off[r] != (uint64_t)sample_size[r] || region_start[r] > region_end[r]) {
+            ctx->err = "window_log2: bad region table"; return CSV_EINVAL;
+        }
+    }
+    const uint64_t nw = win_off[n_regions];
+    if (nw == 0) return CSV_OK;
+    if (!log2_cov || !win_start || !win_end) { ctx->err = "window_log2: null output"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    int rc = arena_reserve(ctx, ctx->arena, align_up((size_t)depth_len * 4, 256) + 3 * align_up(n_regions * 4, 256) + align_up((n_regions + 1) * 8, 256) +
+                                                align_up(nw * 8, 256) + 2 * align_up(nw * 4, 256) + 4096);
+    if (rc) return rc;
+    Arena &a = ctx->arena;
+    uint32_t *dd = (uint32_t *)arena_alloc(a, (size_t)depth_len * 4), *drs = (uint32_t *)arena_alloc(a, n_regions * 4), *dre = (uint32_t *)arena_alloc(a, n_regions * 4);
+    int32_t *dss = (int32_t *)arena_alloc(a, n_regions * 4);
+    uint64_t *dwo = (uint64_t *)arena_alloc(a, (n_regions + 1) * 8);
+    double *dl2 = (double *)arena_alloc(a, nw * 8);
+    uint32_t *dws = (uint32_t *)arena_alloc(a, nw * 4), *dwe = (uint32_t *)arena_alloc(a, nw * 4);
+    if (!dd || !drs || !dre || !dss || !dwo || !dl2 || !dws || !dwe) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    hipStream_t s = ctx->stream;
+    CSV_HIP(ctx, hipMemcpyAsync(dd, depth, (size_t)depth_len * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(drs, region_start, n_regions * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(dre, region_end, n_regions * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(dss, sample_size, n_regions * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(dwo, win_off, (n_regions + 1) * 8, hipMemcpyHostToDevice, s));
+    if ((rc = csvgpu_window_log2_dev(ctx, dd, depth_len, drs, dre, dss, dwo, n_regions, nw, mean_cov, dl2, dws, dwe))) return rc;
+    CSV_HIP(ctx, hipMemcpyAsync(log2_cov, dl2, nw * 8, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipMemcpyAsync(win_start, dws, nw * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipMemcpyAsync(win_end, dwe, nw * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipStreamSynchronize(s));
+    return CSV_OK;
+}
+
+int csvgpu_viterbi_dev(csv_ctx *ctx, const csv_hmm *hmm, const double *d_o1, const double *d_o2, const double *d_pfb,
+                       const uint64_t *d_seq_off, uint64_t n_seq, uint64_t n_obs, int32_t *d_states, double *d_loglik)
+{
+    if (!ctx) return CSV_EINVAL;
+    if (!hmm) { ctx->err = "viterbi: null hmm"; return CSV_EINVAL; }
+    if (n_seq == 0) return CSV_OK;
+    if (!d_seq_off || !d_loglik || (n_obs && (!d_o1 || !d_o2 || !d_pfb || !d_states))) { ctx->err = "viterbi: null array"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    int rc = arena_reserve(ctx, ctx->work, viterbi_tmp_bytes(n_obs, n_seq) + 1024);
+    if (rc) return rc;
+    void *tmp = arena_alloc(ctx->work, viterbi_tmp_bytes(n_obs, n_seq));
+    if (!tmp) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    TimerScope ts(ctx, CSV_K_VITERBI);
+    launch_viterbi(ctx->stream, *hmm, d_o1, d_o2, d_pfb, d_seq_off, n_seq, n_obs, d_states, d_loglik, tmp);
+    return CSV_OK;
+}
+
+int csvgpu_viterbi(csv_ctx *ctx, const csv_hmm *hmm, const double *o1, const double *o2, const double *pfb,
+                   const uint64_t *seq_off, uint64_t n_seq, int32_t *states, double *loglik)
+{
+    if (!ctx) return CSV_EINVAL;
+    if (!hmm) { ctx->err = "viterbi: null hmm"; return CSV_EINVAL; }
+    if (n_seq == 0) return CSV_OK;
+    if (!seq_off || !loglik) { ctx->err = "viterbi: null array"; return CSV_EINVAL; }
+    for (uint64_t s = 0; s < n_seq; s++) if (seq_off[s + 1] < seq_off[s]) { ctx->err = "viterbi: seq_off not monotone"; return CSV_EINVAL; }
+    const uint64_t n = seq_off[n_seq];
+    if (n && (!o1 || !o2 || !pfb || !states)) { ctx->err = "viterbi: null array"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    int rc = arena_reserve(ctx, ctx->arena, 3 * align_up(n * 8, 256) + align_up((n_seq + 1) * 8, 256) + align_up(n * 4, 256) + align_up(n_seq * 8, 256) + 4096);
+    if (rc) return rc;
+    Arena &a = ctx->arena;
+    double *d1 = (double *)arena_alloc(a, n * 8 + 8), *d2 = (double *)arena_alloc(a, n * 8 + 8), *dp = (double *)arena_alloc(a, n * 8 + 8);
+    uint64_t *doff = (uint64_t *)arena_alloc(a, (n_seq + 1) * 8);
+    int32_t *dst = (int32_t *)arena_alloc(a, n * 4 + 8);
+    double *dll = (double *)arena_alloc(a, n_seq * 8);
+    if (!d1 || !d2 || !dp || !doff || !dst || !dll) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    hipStream_t s = ctx->stream;
+    if (n) {
+        CSV_HIP(ctx, hipMemcpyAsync(d1, o1, n * 8, hipMemcpyHostToDevice, s));
+        CSV_HIP(ctx, hipMemcpyAsync(d2, o2, n * 8, hipMemcpyHostToDevice, s));
+        CSV_HIP(ctx, hipMemcpyAsync(dp, pfb, n * 8, hipMemcpyHostToDevice, s));
+    }
+    CSV_HIP(ctx, hipMemcpyAsync(doff, seq_off, (n_seq + 1) * 8, hipMemcpyHostToDevice, s));
+    if ((rc = csvgpu_viterbi_dev(ctx, hmm, d1, d2, dp, doff, n_seq, n, dst, dll))) return rc;
+    if (n) CSV_HIP(ctx, hipMemcpyAsync(states, dst, n * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipMemcpyAsync(loglik, dll, n_seq * 8, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipStreamSynchronize(s));
+    return CSV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resident shards + the per-chromosome pipeline
+
+static void shard_release(csv_shard *sh)
+{
+    if (!sh) return;
+    if (sh->owned) {
+        (void)hipFree((void *)sh->d.pos); (void)hipFree((void *)sh->d.flag); (void)hipFree((void *)sh->d.mapq);
+        (void)hipFree((void *)sh->d.cigar_off); (void)hipFree((void *)sh->d.cigar);
+    }
+    (void)hipFree(sh->ref_end); (void)hipFree(sh->q_start); (void)hipFree(sh->q_end);
+    (void)hipFree(sh->depth); (void)hipFree(sh->sig_raw); (void)hipFree(sh->scratch); (void)hipFree(sh->counters);
+    delete sh;
+}
+
+static csv_shard *shard_common(csv_ctx *ctx, csv_shard *sh)
+{
+    const uint64_t n = sh->d.n_reads;
+    bool ok = true;
+    ok &= hipMalloc((void **)&sh->ref_end, n * 4 + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->q_start, n * 4 + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->q_end, n * 4 + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->depth, (size_t)sh->depth_len * 4 + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->counters, 256) == hipSuccess;
+    sh->sig_cap = std::max<uint64_t>(1u << 18, n * 2);
+    ok &= hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); ctx->err = "hipMalloc failed (shard)"; shard_release(sh); return nullptr; }
+    return sh;
+}
+
+csv_shard *csvgpu_shard_upload(csv_ctx *ctx, const csv_reads *r, uint32_t depth_len)
+{
+    if (check_reads(ctx, r)) return nullptr;
+    (void)hipSetDevice(ctx->device);
+    csv_shard *sh = new (std::nothrow) csv_shard();
+    if (!sh) { ctx->err = "out of host memory"; return nullptr; }
+    sh->owned = true; sh->depth_len = depth_len; sh->d = *r; sh->d.tid = nullptr;
+    sh->d.pos = nullptr; sh->d.flag = nullptr; sh->d.mapq = nullptr; sh->d.cigar_off = nullptr; sh->d.cigar = nullptr;
+    const uint64_t n = r->n_reads, m = r->n_cigar;
+    bool ok = true;
+    ok &= hipMalloc((void **)&sh->d.pos, n * 4 + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->d.flag, n * 2 + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->d.mapq, n + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->d.cigar_off, (n + 1) * 8) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->d.cigar, m * 4 + 16) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); ctx->err = "hipMalloc failed (shard upload)"; shard_release(sh); return nullptr; }
+    hipStream_t s = ctx->stream;
+    bool cp = true;
+    if (n) {
+        cp &= hipMemcpyAsync((void *)sh->d.pos, r->pos, n * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+        cp &= hipMemcpyAsync((void *)sh->d.flag, r->flag, n * 2, hipMemcpyHostToDevice, s) == hipSuccess;
+        cp &= hipMemcpyAsync((void *)sh->d.mapq, r->mapq, n, hipMemcpyHostToDevice, s) == hipSuccess;
+    }
+    cp &= hipMemcpyAsync((void *)sh->d.cigar_off, r->cigar_off, (n + 1) * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (m) cp &= hipMemcpyAsync((void *)sh->d.cigar, r->cigar, m * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+    cp &= hipStreamSynchronize(s) == hipSuccess;
+    if (!cp) { ctx->err = "H2D copy failed (shard upload)"; shard_release(sh); return nullptr; }
+    return shard_common(ctx, sh);
+}
+
+csv_shard *csvgpu_shard_wrap_dev(csv_ctx *ctx, const csv_reads *r, uint32_t depth_len)
+{
+    if (check_reads(ctx, r)) return nullptr;
+    (void)hipSetDevice(ctx->device);
+    csv_shard *sh = new (std::nothrow) csv_shard();
+    if (!sh) { ctx->err = "out of host memory"; return nullptr; }
+    sh->owned = false; sh->depth_len = depth_len; sh->d = *r;
+    return shard_common(ctx, sh);
+}
+
+void csvgpu_shard_free(csv_ctx *ctx, csv_shard *sh)
+{
+    if (!ctx || !sh) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    shard_release(sh);
+}
+
+int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
+                            csv_chr_result *res)
+{
+    if (!ctx || !sh || !res) return CSV_EINVAL;
+    if (!(eps >= 0.0) || !(eps < 1.0)) { ctx->err = "pipeline: eps must be in [0,1)"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    ScanCounters *cnt = (ScanCounters *)sh->counters;
+    ScanCounters h;
+    int rc;
+    for (int attempt = 0;; attempt++) {
+        CSV_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(ScanCounters), s));
+        {
+            TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
+            launch_cigar_scan(s, ctx->n_cu, sh->d, sh->depth_len, min_oplen, min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
+                              sh->q_start, sh->q_end, cnt);
+        }
+        if ((rc = read_counters(ctx, cnt, h))) return rc;                 // the one mid-pipeline host sync
+        if (h.n_sig <= sh->sig_cap) break;
+        if (attempt) { ctx->err = "pipeline: signature buffer overflow twice"; return CSV_ENOMEM; }
+        CSV_HIP(ctx, hipFree(sh->sig_raw));
+        sh->sig_raw = nullptr; sh->sig_cap = h.n_sig + h.n_sig / 8 + 1024;
+        CSV_HIP(ctx, hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)));
+    }
+    const uint64_t n = h.n_sig, n_del = h.n_del, n_ins = n - n_del;
+
+    // shard scratch: sorted signatures, SoA start/end, labels, sort + dbscan workspace (grow-only)
+    const uint64_t n_big = std::max(n_del, n_ins);
+    const size_t need = align_up(n * sizeof(csv_sig), 256) + 3 * align_up(n * 4 + 16, 256) + sortws_bytes(n) + dbscan_tmp_bytes(n_big) + 4096;
+    if (need > sh->scratch_cap) {
+        if (sh->scratch) CSV_HIP(ctx, hipFree(sh->scratch));
+        sh->scratch = nullptr; sh->scratch_cap = 0;
+        CSV_HIP(ctx, hipMalloc((void **)&sh->scratch, need + need / 4));
+        sh->scratch_cap = need + need / 4;
+    }
+    Arena sa; sa.base = sh->scratch; sa.cap = sh->scratch_cap; sa.used = 0;
+    csv_sig *sig_sorted = (csv_sig *)arena_alloc(sa, n * sizeof(csv_sig));
+    uint32_t *st = (uint32_t *)arena_alloc(sa, n * 4 + 16), *en = (uint32_t *)arena_alloc(sa, n * 4 + 16);
+    int32_t *labels = (int32_t *)arena_alloc(sa, n * 4 + 16);
+    SortWs w;
+    const bool ws_ok = sortws_carve(sa, n, w);
+    void *db_tmp = arena_alloc(sa, dbscan_tmp_bytes(n_big));
+    if (!sig_sorted || !st || !en || !labels || !ws_ok || !db_tmp) { ctx->err = "shard scratch exhausted"; return CSV_ENOMEM; }
+
+    // depth map + mean coverage + min_pts (device scalar)
+    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads)))) return rc;
+    if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, h.unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
+    launch_min_pts(s, cnt, min_pts_pct);
+
+    // ordering: DEL calls then INS calls, each in chr_sv_calls order
+    order_signatures(ctx, sh->sig_raw, n, h.max_start, h.max_len, true, w, sig_sorted, st, en);
+
+    // per-type interval DBSCAN (mergeSVs walks DEL ... INS, sv_object.cpp:62-68)
+    {
+        TimerScope ts(ctx, CSV_K_DBSCAN);
+        if (n_del) launch_dbscan_iv_sorted(s, st, en, nullptr, n_del, eps, 0, &cnt->min_pts, labels, db_tmp);
+        if (n_ins) launch_dbscan_iv_sorted(s, st + n_del, en + n_del, nullptr, n_ins, eps, 0, &cnt->min_pts, labels + n_del, db_tmp);
+    }
+    if ((rc = read_counters(ctx, cnt, h))) return rc;                     // final sync: scalars for the caller
+    res->n_sig = n; res->n_del = n_del; res->n_ins = n_ins;
+    res->depth_sum = h.depth_sum; res->depth_nonzero = h.depth_nonzero; res->min_pts = h.min_pts; res->mean_cov = h.mean_cov;
+    res->sig_del = sig_sorted; res->sig_ins = sig_sorted + n_del;
+    res->label_del = labels; res->label_ins = labels + n_del;
+    res->depth = sh->depth; res->ref_end = sh->ref_end; res->q_start = sh->q_start; res->q_end = sh->q_end;
+    return CSV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// devutil.hpp — wave64 device helpers (gfx950). Device code only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace csv {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int32_t wave_incl_max(int32_t v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int32_t t = __shfl_up(v, d, 64);
+        if (l >= d) v = max(v, t);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// The reference's interval metric, evaluated in the same IEEE double expression
+// (dbscan.cpp:69-81): 1.0 - std::min(ov/len1, ov/len2) <= eps, with std::min(a,b) = (b<a)?b:a
+// (NaN-asymmetric when a length is 0). Build with -ffp-contract=off.
+__device__ __forceinline__ bool iv_neighbor(uint32_t s1, uint32_t e1, uint32_t s2, uint32_t e2, double eps)
+{
+    int a = min((int)e1, (int)e2);
+    int b = max((int)s1, (int)s2);
+    int overlap = max(0, a - b);
+    int length1 = (int)(e1 - s1);
+    int length2 = (int)(e2 - s2);
+    double x = (double)overlap / (double)length1;
+    double y = (double)overlap / (double)length2;
+    double mn = (y < x) ? y : x;
+    return (1.0 - mn) <= eps;
+}
+
+}  // namespace csv

@@ -1,0 +1,281 @@
+// sort.hip — ordering pass (gfx950): stable LSD radix sort + the tie rule of addSVCall.
+//
+// The reference keeps one vector per chromosome sorted by (start,end) with std::lower_bound inserts
+// (sv_object.cpp:22-33), so equal (start,end) calls end up in REVERSE insertion order. That order is
+// DBSCAN's index order and decides which member std::sort leaves at the representative's slot, so it
+// is reproduced exactly: (1) radix-sort (type | start | end-start) keys, (2) inside each run of equal
+// keys rank the members by (read, query offset) descending — the insertion order of the reference is
+// (read ascending, CIGAR order), and the query offset grows along the CIGAR for ops at one position.
+//
+// Radix sort: 8-bit digits, one 64-lane wave owns a tile of 2048 keys and walks it in 32 rounds of
+// 64 (round-major = index order). Ranks inside a round come from an 8-ballot match-any, per-digit
+// running offsets live in the wave's private 1 KiB of LDS, so the scatter is stable without any
+// workgroup barrier. Three small kernels per pass: histogram, exclusive scan of the (digit, tile)
+// table, scatter. Only as many passes as the keys have bits.
+#include "../common.hpp"
+#include "../devutil.hpp"
+
+namespace csv {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / WAVE;
+constexpr int RS_ROUNDS = 32;
+constexpr int RS_TILE = RS_ROUNDS * WAVE;     // 2048 keys per wave
+constexpr int RS_BINS = 256;
+
+// ------------------------------------------------------------------------------- generic exclusive sum (u32)
+constexpr int ES_THREADS = 256;
+constexpr int ES_ITEMS = 8;
+constexpr int ES_TILE = ES_THREADS * ES_ITEMS;
+
+__global__ __launch_bounds__(ES_THREADS) void es_reduce_kernel(const uint32_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ blk)
+{
+    __shared__ uint32_t ws[ES_THREADS / WAVE];
+    const uint64_t b0 = (uint64_t)blockIdx.x * ES_TILE;
+    uint32_t m = 0;
+    for (int k = 0; k < ES_ITEMS; k++) {
+        uint64_t i = b0 + (uint64_t)k * ES_THREADS + threadIdx.x;
+        if (i < n) m += in[i];
+    }
+    m = wave_sum(m);
+    if (lane_id() == 0) ws[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < ES_THREADS / WAVE; w++) m += ws[w];
+        blk[blockIdx.x] = m;
+    }
+}
+
+__global__ __launch_bounds__(ES_THREADS) void es_spine_kernel(uint32_t *blk, uint64_t nb)
+{
+    __shared__ uint32_t ws[ES_THREADS / WAVE];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t b0 = 0; b0 < nb; b0 += ES_THREADS) {
+        const uint64_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? blk[i] : 0u;
+        const uint32_t inc = wave_incl_sum(v);
+        if (lane_id() == 63) ws[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t pre = carry_s;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pre += ws[w];
+        if (i < nb) blk[i] = pre + inc - v;
+        __syncthreads();
+        if (threadIdx.x == ES_THREADS - 1) carry_s = pre + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(ES_THREADS) void es_down_kernel(uint32_t *__restrict__ data, uint64_t n, const uint32_t *__restrict__ blk)
+{
+    __shared__ uint32_t ws[ES_THREADS / WAVE];
+    const uint64_t b0 = (uint64_t)blockIdx.x * ES_TILE + (uint64_t)threadIdx.x * ES_ITEMS;
+    uint32_t v[ES_ITEMS], m = 0;
+#pragma unroll
+    for (int k = 0; k < ES_ITEMS; k++) { v[k] = (b0 + k < n) ? data[b0 + k] : 0u; m += v[k]; }
+    const uint32_t inc = wave_incl_sum(m);
+    if (lane_id() == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t pre = blk[blockIdx.x] + inc - m;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pre += ws[w];
+#pragma unroll
+    for (int k = 0; k < ES_ITEMS; k++) {
+        if (b0 + k < n) data[b0 + k] = pre;
+        pre += v[k];
+    }
+}
+
+size_t exclusive_sum_tmp_bytes(uint64_t n) { return align_up(((n + ES_TILE - 1) / ES_TILE + 1) * sizeof(uint32_t), 256); }
+
+void launch_exclusive_sum_u32(hipStream_t s, uint32_t *data, uint64_t n, void *tmp)
+{
+    if (n == 0) return;
+    const uint64_t nb = (n + ES_TILE - 1) / ES_TILE;
+    uint32_t *blk = (uint32_t *)tmp;
+    hipLaunchKernelGGL(es_reduce_kernel, dim3((unsigned)nb), dim3(ES_THREADS), 0, s, data, n, blk);
+    hipLaunchKernelGGL(es_spine_kernel, dim3(1), dim3(ES_THREADS), 0, s, blk, nb);
+    hipLaunchKernelGGL(es_down_kernel, dim3((unsigned)nb), dim3(ES_THREADS), 0, s, data, n, blk);
+}
+
+// ------------------------------------------------------------------------------- radix sort passes
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n, int shift,
+                                                            uint32_t *__restrict__ table, uint32_t n_tiles)
+{
+    __shared__ uint32_t hist[RS_WAVES][RS_BINS];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t tile = (uint64_t)blockIdx.x * RS_WAVES + wave;
+    for (int b = lane; b < RS_BINS; b += WAVE) hist[wave][b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (tile < n_tiles) {
+        const uint64_t t0 = tile * RS_TILE;
+        for (int rd = 0; rd < RS_ROUNDS; rd++) {
+            const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
+            if (i < n) atomicAdd(&hist[wave][(keys[i] >> shift) & 0xff], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int b = lane; b < RS_BINS; b += WAVE) table[(uint64_t)b * n_tiles + tile] = hist[wave][b];
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                               uint64_t n, int shift, const uint32_t *__restrict__ table,
+                                                               uint32_t n_tiles, uint64_t *__restrict__ keys_out,
+                                                               uint32_t *__restrict__ vals_out)
+{
+    __shared__ uint32_t offs[RS_WAVES][RS_BINS];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t tile = (uint64_t)blockIdx.x * RS_WAVES + wave;
+    if (tile >= n_tiles) return;
+    for (int b = lane; b < RS_BINS; b += WAVE) offs[wave][b] = table[(uint64_t)b * n_tiles + tile];
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t t0 = tile * RS_TILE;
+    const uint64_t lt = lanemask_lt();
+    for (int rd = 0; rd < RS_ROUNDS; rd++) {
+        const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
+        const bool valid = i < n;
+        uint64_t key = 0; uint32_t val = 0;
+        if (valid) { key = keys_in[i]; val = vals_in[i]; }
+        const uint32_t d = (uint32_t)(key >> shift) & 0xffu;
+        uint64_t mask = __ballot(valid);
+        if (mask == 0) break;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        // mask = valid lanes of this round with my digit
+        uint32_t base = 0;
+        if (valid) base = offs[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rank = (uint32_t)__popcll(mask & lt);
+        if (valid && rank == 0) offs[wave][d] = base + (uint32_t)__popcll(mask);   // leader advances the digit's cursor
+        __builtin_amdgcn_wave_barrier();
+        if (valid) { keys_out[base + rank] = key; vals_out[base + rank] = val; }
+    }
+}
+
+size_t radix_sort_tmp_bytes(uint64_t n)
+{
+    const uint64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
+    const uint64_t tab = (uint64_t)RS_BINS * (n_tiles ? n_tiles : 1);
+    return align_up(tab * sizeof(uint32_t), 256) + exclusive_sum_tmp_bytes(tab);
+}
+
+int launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_out, uint32_t *vals_out,
+                          uint64_t n, int key_bits, void *tmp)
+{
+    if (n <= 1 || key_bits <= 0) return 0;
+    const uint32_t n_tiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    const uint64_t tab = (uint64_t)RS_BINS * n_tiles;
+    uint32_t *table = (uint32_t *)tmp;
+    void *es_tmp = (char *)tmp + align_up(tab * sizeof(uint32_t), 256);
+    const unsigned grid = (n_tiles + RS_WAVES - 1) / RS_WAVES;
+    const int passes = (key_bits + 7) / 8;
+    uint64_t *ki = keys_in, *ko = keys_out;
+    uint32_t *vi = vals_in, *vo = vals_out;
+    for (int p = 0; p < passes; p++) {
+        const int shift = p * 8;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, n, shift, table, n_tiles);
+        launch_exclusive_sum_u32(s, table, tab, es_tmp);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, vi, n, shift, table, n_tiles, ko, vo);
+        uint64_t *tk = ki; ki = ko; ko = tk;
+        uint32_t *tv = vi; vi = vo; vo = tv;
+    }
+    return (passes & 1) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------- signature ordering
+// key = [type bit | start | end-start]; type bit 0 = DEL, 1 = INS so the DEL calls come first
+// (mergeSVs walks DEL, DUP, INV, INS, BND — sv_object.cpp:62-68). type_bit_pos < 0: no type bit
+// (the interleaved order of the reference's single chr_sv_calls vector).
+__global__ void sig_make_keys_kernel(const csv_sig *__restrict__ sig, uint64_t n, int len_bits, int type_bit_pos,
+                                     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const csv_sig s = sig[i];
+    uint64_t k = ((uint64_t)s.start << len_bits) | (uint64_t)(s.end - s.start);
+    if (type_bit_pos >= 0 && (s.qpos_kind & 3u) != CSV_KIND_DEL) k |= 1ull << type_bit_pos;
+    keys[i] = k;
+    vals[i] = (uint32_t)i;
+}
+
+void launch_sig_make_keys(hipStream_t s, const csv_sig *sig, uint64_t n, int len_bits, int type_bit_pos,
+                          uint64_t *keys, uint32_t *vals)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(sig_make_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sig, n, len_bits, type_bit_pos, keys, vals);
+}
+
+// Inside a run of equal keys the reference order is reverse insertion order: later read first, and
+// within one read the later CIGAR op (larger query offset) first. Each thread ranks its element
+// inside its run (runs are as long as the local coverage at most) and writes the final record.
+__global__ void sig_fix_ties_gather_kernel(const csv_sig *__restrict__ sig_raw, const uint64_t *__restrict__ keys,
+                                           const uint32_t *__restrict__ vals, uint64_t n, csv_sig *__restrict__ sig_sorted,
+                                           uint32_t *__restrict__ start_out, uint32_t *__restrict__ end_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    const csv_sig me = sig_raw[vals[i]];
+    uint64_t pos = i;
+    const bool tie_l = i > 0 && keys[i - 1] == k, tie_r = i + 1 < n && keys[i + 1] == k;
+    if (tie_l || tie_r) {
+        uint64_t a = i, b = i + 1;
+        while (a > 0 && keys[a - 1] == k) a--;
+        while (b < n && keys[b] == k) b++;
+        const uint64_t mine = ((uint64_t)me.read << 32) | me.qpos_kind;
+        uint64_t rank = 0;
+        for (uint64_t j = a; j < b; j++) {
+            const csv_sig o = sig_raw[vals[j]];
+            rank += (((uint64_t)o.read << 32) | o.qpos_kind) > mine;
+        }
+        pos = a + rank;
+    }
+    sig_sorted[pos] = me;
+    if (start_out) { start_out[pos] = me.start; end_out[pos] = me.end; }
+}
+
+void launch_sig_fix_ties_gather(hipStream_t s, const csv_sig *sig_raw, const uint64_t *keys, const uint32_t *vals,
+                                uint64_t n, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(sig_fix_ties_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sig_raw, keys, vals, n,
+                       sig_sorted, start_out, end_out);
+}
+
+// ------------------------------------------------------------------------------- small helpers
+__global__ void iota_keys_u32_kernel(const uint32_t *__restrict__ k32, uint64_t n, uint64_t *keys, uint32_t *vals)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = k32[i]; vals[i] = (uint32_t)i; }
+}
+__global__ void iota_keys_i32_kernel(const int32_t *__restrict__ k32, uint64_t n, uint64_t *keys, uint32_t *vals)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = (uint32_t)k32[i] ^ 0x80000000u; vals[i] = (uint32_t)i; }
+}
+__global__ void check_sorted_u32_kernel(const uint32_t *__restrict__ k, uint64_t n, unsigned int *flag)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > 0 && i < n && k[i] < k[i - 1]) *flag = 1u;
+}
+__global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint64_t n, uint32_t *dst)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+#define GRID1D(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+void launch_iota_keys_u32(hipStream_t s, const uint32_t *k32, uint64_t n, uint64_t *keys, uint32_t *vals)
+{ if (n) hipLaunchKernelGGL(iota_keys_u32_kernel, GRID1D(n), 0, s, k32, n, keys, vals); }
+void launch_iota_keys_i32(hipStream_t s, const int32_t *k32, uint64_t n, uint64_t *keys, uint32_t *vals)
+{ if (n) hipLaunchKernelGGL(iota_keys_i32_kernel, GRID1D(n), 0, s, k32, n, keys, vals); }
+void launch_check_sorted_u32(hipStream_t s, const uint32_t *k, uint64_t n, unsigned int *flag)
+{ if (n) hipLaunchKernelGGL(check_sorted_u32_kernel, GRID1D(n), 0, s, k, n, flag); }
+void launch_gather_u32(hipStream_t s, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst)
+{ if (n) hipLaunchKernelGGL(gather_u32_kernel, GRID1D(n), 0, s, src, idx, n, dst); }
+
+}  // namespace csv

@@ -205,9 +205,8 @@ typedef struct csv_chr_result {
     uint32_t        depth_nonzero;
     int32_t         min_pts;      /* ceil(mean_cov * min_pts_pct) or 5 (sv_caller.cpp:723-728) */
     double          mean_cov;
-    const csv_sig  *sig;          /* [n_sig] in chr_sv_calls order (all kinds interleaved) */
-    const csv_sig  *sig_del;      /* [n_del] the DEL subsequence (std::copy_if order, sv_object.cpp:80) */
-    const csv_sig  *sig_ins;      /* [n_ins] the INS subsequence */
+    const csv_sig  *sig_del;      /* [n_del] the DEL calls of chr_sv_calls, in vector order (std::copy_if, sv_object.cpp:80) */
+    const csv_sig  *sig_ins;      /* [n_ins] the INS calls (CIGARINS + CIGARCLIP), in vector order */
     const int32_t  *label_del;    /* [n_del] DBSCAN labels of sig_del */
     const int32_t  *label_ins;    /* [n_ins] DBSCAN labels of sig_ins */
     const uint32_t *depth;        /* [depth_len] */
@@ -230,6 +229,11 @@ int csvgpu_dbscan_iv_dev(csv_ctx *ctx, const uint32_t *d_start, const uint32_t *
 int csvgpu_dbscan_1d_dev(csv_ctx *ctx, const int32_t *d_pts, const uint64_t *d_seg_off,
                          uint64_t n_seg, uint64_t n_pts, uint32_t max_seg_len,
                          double eps, int32_t min_pts, int32_t *d_labels);
+int csvgpu_window_log2_dev(csv_ctx *ctx, const uint32_t *d_depth, uint32_t depth_len,
+                           const uint32_t *d_region_start, const uint32_t *d_region_end,
+                           const int32_t *d_sample_size, const uint64_t *d_win_off, uint64_t n_regions,
+                           uint64_t n_windows, double mean_cov, double *d_log2_cov,
+                           uint32_t *d_win_start, uint32_t *d_win_end);
 int csvgpu_viterbi_dev(csv_ctx *ctx, const csv_hmm *hmm, const double *d_o1, const double *d_o2,
                        const double *d_pfb, const uint64_t *d_seq_off, uint64_t n_seq,
                        uint64_t n_obs, int32_t *d_states, double *d_loglik);

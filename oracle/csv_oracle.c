@@ -91,7 +91,7 @@ int64_t orc_cigar_scan(uint64_t n_reads, const int32_t *pos_a, const uint16_t *f
                     s.qpos_kind = (query_pos << 2) | 0u; /* CIGARINS */
                     per_read[m++] = s;
                 } else if (op == OP_S) {                 /* :599 */
-                    if ((uint64_t)pos + 1 >= (uint64_t)depth_len)
+                    if ((size_t)(uint32_t)(pos + 1u) >= (size_t)depth_len)   /* uint32 `pos + 1` vs size_t size() */
                         continue;                        /* :602-604 — also skips :648-655 */
                     orc_sig s;
                     s.start = pos + 1;                   /* :619 */
