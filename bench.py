@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — hot-path benchmark (driver contract: one JSON line on rank 0).
+
+A "step" is one full pass of the CIGAR path over one synthetic chromosome that is already resident in
+HBM: CIGAR scan (signatures + alignment intervals) -> tile-owner depth map + mean coverage + min_pts ->
+ordering -> per-type interval DBSCAN on the GPU, then labels/signatures back to the host and the
+mergeSVs representative choice in the C++ host mirror (i.e. up to the reference's chr_sv_calls after
+mergeSVs). Workload at N=1 = BASELINE.json configs[1]: chr22, 30x synthetic ONT.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own chromosome-sized
+shard (weak scaling, chromosomes shard with no data-path collective); the only collective is the final
+gather of the merged call records to rank 0 (RCCL all_gather of a fixed-size padded buffer), once per step.
+
+value = reads scanned / s over all ranks; signatures clustered / s is reported beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CHR22_LEN = 50818468
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+GATHER_CAP = 8192              # merged calls per rank carried by the final gather
+REC_I32 = 12                   # one merged call record = 48 B (host.CALL_DTYPE)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chr-len", type=int, default=CHR22_LEN)
+    ap.add_argument("--depth", type=float, default=30.0)
+    ap.add_argument("--tech", choices=["ont", "hifi"], default="ont")
+    ap.add_argument("--eps", type=float, default=0.1)
+    ap.add_argument("--min-pts-pct", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frac", type=float, default=1.0, help="fraction of the shard's reads given to the CPU baseline")
+    args = ap.parse_args()
+
+    import torch
+    import contextsv_amd as cs
+    from contextsv_amd import host
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    # ---- synthetic shard: seed = 0x5EED0000 + 1000*config + chr_index ------------
+    tech = 0 if args.tech == "ont" else 1
+    gen_threads = max(1, (os.cpu_count() or 8) // max(world, 1))
+    t0 = time.time()
+    syn = host.SynthShard(0x5EED0000 + 1000 * 1 + 22 + rank, args.chr_len, args.depth, tech, min(gen_threads, 16))
+    reads, depth_len = syn.reads, syn.depth_len
+    t_gen = time.time() - t0
+
+    ctx = cs.Context(dev.index)
+    host.set_context(ctx)
+    t0 = time.time()
+    shard = ctx.upload(reads, depth_len)
+    ctx.synchronize()
+    t_upload = time.time() - t0
+    h2d_bytes = reads.cigar.nbytes + reads.pos.nbytes + reads.flag.nbytes + reads.mapq.nbytes + reads.cigar_off.nbytes
+
+    gather_buf = torch.zeros(GATHER_CAP * REC_I32 + 2, dtype=torch.int32, device=dev) if world > 1 else None
+    gather_out = torch.zeros(world * (GATHER_CAP * REC_I32 + 2), dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        calls, tags, st = host.process_resident_chromosome(ctx, shard, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
+        if world > 1:
+            # final gather of the merged call records to rank 0 (the path's only exchange step)
+            n = len(calls)
+            rec = np.zeros(GATHER_CAP * REC_I32 + 2, np.int32)
+            rec[0] = n
+            rec[2:2 + n * REC_I32] = np.frombuffer(calls.tobytes(), dtype=np.int32)
+            gather_buf.copy_(torch.from_numpy(rec), non_blocking=False)
+            dist.all_gather_into_tensor(gather_out, gather_buf)
+            if rank == 0:
+                _ = gather_out[:: GATHER_CAP * REC_I32 + 2].cpu()     # per-rank counts land on the host
+        return calls, st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    st = None
+    calls = None
+    for _ in range(args.steps):
+        calls, st = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = ctx.timing()
+    ctx.timing_enable(False)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(reads.n_reads), float(st.n_signatures), float(reads.n_cigar)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    reads_all, sigs_all, ops_all = (float(x) for x in tot.tolist())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        # per-kernel device time from HIP events recorded on the kernels' own stream, inside the timed region
+        kern = {k: (ms / n if n else 0.0) for k, (ms, n) in timing.items()}
+        # dbscan group = two fits (DEL + INS) per step in one timer scope; scan/depth/sort one scope per step
+        alg_bytes = {
+            "cigar_scan": 4.0 * reads.n_cigar + 23.0 * reads.n_reads + 16.0 * st.n_signatures,
+            "depth": 4.0 * reads.n_cigar + 4.0 * depth_len,
+            "sort": 16.0 * st.n_signatures * 2,
+            "dbscan": 12.0 * st.n_signatures,
+        }
+        dominant = max(alg_bytes.keys(), key=lambda k: kern.get(k, 0.0))
+        ach = alg_bytes[dominant] / (kern[dominant] * 1e-3) / 1e9 if kern.get(dominant, 0) > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(dominant)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "long reads scanned/s (CIGAR scan + depth + DBSCAN cluster + merge), synthetic 30x ONT",
+            "value": reads_all * args.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"chr22-sized contig ({args.chr_len} bp), {args.depth:g}x synthetic {args.tech.upper()}, 1 contig per GPU"
+                                   " — CIGAR scan + depth + ordering + interval DBSCAN + mergeSVs (BASELINE.json configs[1])",
+                       "reads_per_gpu": int(reads.n_reads), "cigar_ops_per_gpu": int(reads.n_cigar),
+                       "signatures_per_gpu": int(st.n_signatures), "merged_calls_per_gpu": int(st.n_calls),
+                       "eps": args.eps, "min_pts_pct": args.min_pts_pct, "min_pts": int(st.min_pts), "parallelism": f"chromosome-shard x{world}"},
+            "signatures_clustered_per_s": sigs_all * args.steps / elapsed,
+            "cigar_ops_per_s": ops_all * args.steps / elapsed,
+            "kernel_ms_per_step": {k: round(v, 5) for k, v in kern.items() if v > 0},
+            "host_merge_ms_per_step": round(st.ms_host_merge, 4),
+            "device_chain_ms_last_step": round(st.ms_device, 4),
+            "staging": {"h2d_bytes": int(h2d_bytes), "h2d_s": round(t_upload, 4), "synth_s": round(t_gen, 3),
+                        "pcie_inclusive_reads_per_s": reads.n_reads / (t_upload + elapsed / args.steps)},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes[dominant], "kernel_ms": kern.get(dominant, 0.0),
+                         "all": {k: {"ms": round(kern.get(k, 0.0), 5), "GBps": round(alg_bytes[k] / (kern[k] * 1e-3) / 1e9, 2) if kern.get(k, 0) > 0 else None}
+                                 for k in alg_bytes}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(reads, depth_len, args, st)
+        print(json.dumps(out), flush=True)
+
+    shard.free()
+    ctx.close()
+    syn.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(reads, depth_len, args, st):
+    """The CPU restatement (oracle, kind "port") timed on this host, single thread, on a bounded sample of
+    the same workload: the first `frac` of the shard's reads through scan -> depth -> per-type O(n^2) DBSCAN
+    (the reference's structure: three passes, brute-force regionQuery)."""
+    import oracle_lib
+    from contextsv_amd import Reads
+    orc = oracle_lib.load_oracle()
+    n = max(1, int(reads.n_reads * args.cpu_sample_frac))
+    m = int(reads.cigar_off[n])
+    sub = Reads.__new__(Reads)
+    sub.pos, sub.flag, sub.mapq, sub.tid = reads.pos[:n], reads.flag[:n], reads.mapq[:n], None
+    sub.cigar_off, sub.cigar = reads.cigar_off[: n + 1], reads.cigar[:m]
+    t0 = time.perf_counter()
+    sig = orc.cigar_scan(sub, depth_len)
+    t1 = time.perf_counter()
+    _, s, nz = orc.depth(sub, depth_len)
+    t2 = time.perf_counter()
+    mean = s / nz if nz else 0.0
+    min_pts = int(np.ceil(mean * args.min_pts_pct)) if args.min_pts_pct > 0 else 5
+    kind = sig["qpos_kind"] & 3
+    for sel in (kind == 1, kind != 1):
+        part = sig[sel]
+        if len(part) >= 2 and min_pts >= 1:
+            orc.dbscan_iv(part["start"], part["end"], args.eps, min_pts)
+    t3 = time.perf_counter()
+    total = t3 - t0
+    return {"value": n / total, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} of {reads.n_reads} reads of the same shard ({m} CIGAR ops, {len(sig)} signatures): "
+                      f"scan {t1 - t0:.2f}s + depth {t2 - t1:.2f}s + O(n^2) DBSCAN {t3 - t2:.2f}s, oracle/csv_oracle.c -O2, 1 thread",
+            "signatures_clustered_per_s": len(sig) / total, "seconds": total}
+
+
+if __name__ == "__main__":
+    main()

@@ -212,11 +212,9 @@ class Shard:
         def d2h(p, nbytes, dtype):
             if not p or nbytes == 0:
                 return np.zeros(0, dtype)
-            buf = (C.c_char * nbytes)()
-            rc = _hip_memcpy_dtoh(buf, p, nbytes)
-            if rc != 0:
-                raise RuntimeError(f"hipMemcpy D2H failed: {rc}")
-            return np.frombuffer(buf, dtype=dtype).copy()
+            out = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype)
+            self.ctx._check(self.ctx.lib.csvgpu_download(self.ctx.h, out.ctypes.data, p, nbytes))
+            return out
 
         r = res.raw
         out = {
@@ -231,15 +229,3 @@ class Shard:
         if want_depth:
             out["depth"] = d2h(r.depth, self.depth_len * 4, np.uint32)
         return out
-
-
-_hip = None
-
-
-def _hip_memcpy_dtoh(dst, src, nbytes):
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        _hip.hipMemcpy.restype = C.c_int
-    return _hip.hipMemcpy(dst, src, nbytes, 2)  # hipMemcpyDeviceToHost

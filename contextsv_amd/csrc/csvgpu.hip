@@ -703,6 +703,16 @@ void csvgpu_shard_free(csv_ctx *ctx, csv_shard *sh)
     shard_release(sh);
 }
 
+int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!host_dst || !dev_src))) return CSV_EINVAL;
+    if (!bytes) return CSV_OK;
+    (void)hipSetDevice(ctx->device);
+    CSV_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
 int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
                             csv_chr_result *res)
 {

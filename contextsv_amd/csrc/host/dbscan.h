@@ -1,0 +1,41 @@
+// dbscan.h / dbscan1d — the reference's clustering classes (include/dbscan.h:11-33, include/dbscan1d.h:11-32)
+// with fit() forwarded to the HIP kernels through the C-ABI. The context is process-global per thread
+// (one GPU per process): set it once with csvhost::set_context().
+#pragma once
+#include <vector>
+
+#include "../../../include/csvgpu.h"
+#include "sv_object.h"
+
+namespace csvhost {
+void set_context(csv_ctx *ctx);      // borrowed, not owned
+csv_ctx *context();                  // throws std::runtime_error when unset (there is no CPU fallback)
+}
+
+class DBSCAN {
+public:
+    DBSCAN(double epsilon, int minPts) : epsilon(epsilon), minPts(minPts) {}
+    void fit(const std::vector<SVCall> &sv_calls);
+    const std::vector<int> &getClusters() const { return clusters; }
+
+private:
+    double epsilon;
+    int minPts;
+    std::vector<int> clusters;
+};
+
+class DBSCAN1D {
+public:
+    DBSCAN1D(double epsilon, int minPts) : epsilon(epsilon), minPts(minPts) {}
+    void fit(const std::vector<int> &points);
+    const std::vector<int> &getClusters() const { return clusters; }
+    std::vector<int> getLargestCluster(const std::vector<int> &points);
+
+    // batched form: one device call for many point sets (the six fits per overlap group of the split-read path)
+    static void fitBatch(const std::vector<std::vector<int>> &sets, double epsilon, int minPts, std::vector<std::vector<int>> &labels);
+
+private:
+    double epsilon;
+    int minPts;
+    std::vector<int> clusters;
+};

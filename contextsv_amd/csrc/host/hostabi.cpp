@@ -1,0 +1,162 @@
+// hostabi.cpp — extern "C" hooks over the C++ host mirror so the parity tests and bench.py (ctypes)
+// can drive it. POD only; every function returns 0 or -1 (message via csvhost_last_error()).
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "dbscan.h"
+#include "khmm.h"
+#include "log.h"
+#include "sv_caller.h"
+#include "synth.h"
+
+namespace { std::string g_err; }
+#define GUARD(...) try { __VA_ARGS__; return 0; } catch (const std::exception &e) { g_err = e.what(); return -1; }
+
+extern "C" {
+
+// POD view of an SVCall for tests (alt allele / flags travel separately)
+struct csvhost_call {
+    uint32_t start, end;
+    int32_t  sv_type;
+    int32_t  cluster_size;
+    double   hmm_likelihood;
+    int64_t  id;            // caller's tag, carried through merges in aln_offset-independent form
+    uint32_t aln_flags;     // SVEvidenceFlags bits
+    int32_t  genotype, cn_state, aln_offset;
+};
+
+static SVCall from_pod(const csvhost_call &c)
+{
+    SVCall s(c.start, c.end, (SVType)c.sv_type, std::to_string(c.id), SVEvidenceFlags(c.aln_flags), (Genotype)c.genotype,
+             c.hmm_likelihood, c.cn_state, c.aln_offset, c.cluster_size);
+    return s;   // the id rides in alt_allele so it survives every copy the merge makes
+}
+static csvhost_call to_pod(const SVCall &s)
+{
+    csvhost_call c;
+    c.start = s.start; c.end = s.end; c.sv_type = (int32_t)s.sv_type; c.cluster_size = s.cluster_size; c.hmm_likelihood = s.hmm_likelihood;
+    c.id = -1;
+    try { c.id = std::stoll(s.alt_allele); } catch (...) {}
+    c.aln_flags = (uint32_t)s.aln_type.to_ulong(); c.genotype = (int32_t)s.genotype; c.cn_state = s.cn_state; c.aln_offset = s.aln_offset;
+    return c;
+}
+
+const char *csvhost_last_error(void) { return g_err.c_str(); }
+void csvhost_set_context(csv_ctx *ctx) { csvhost::set_context(ctx); }
+void csvhost_set_quiet(int q) { csvhost::set_quiet(q != 0); }
+
+// mergeSVs through the GPU (DBSCAN::fit -> csvgpu_dbscan_iv). out capacity >= n. *n_out = merged count.
+int csvhost_merge_svs(const csvhost_call *calls, uint64_t n, double eps, int32_t min_pts, int keep_noise, csvhost_call *out, uint64_t *n_out)
+{
+    GUARD({
+        std::vector<SVCall> v; v.reserve(n);
+        for (uint64_t i = 0; i < n; i++) v.push_back(from_pod(calls[i]));
+        mergeSVs(v, eps, min_pts, keep_noise != 0);
+        for (size_t i = 0; i < v.size(); i++) out[i] = to_pod(v[i]);
+        *n_out = v.size();
+    })
+}
+
+// the representative choice alone, labels supplied (CPU-testable: no device involved)
+int csvhost_merge_type_with_labels(const csvhost_call *calls, const int32_t *labels, uint64_t n, int keep_noise, csvhost_call *out, uint64_t *n_out)
+{
+    GUARD({
+        std::vector<SVCall> v, merged; v.reserve(n);
+        for (uint64_t i = 0; i < n; i++) v.push_back(from_pod(calls[i]));
+        mergeTypeWithLabels(v, labels, keep_noise != 0, merged);
+        for (size_t i = 0; i < merged.size(); i++) out[i] = to_pod(merged[i]);
+        *n_out = merged.size();
+    })
+}
+
+int csvhost_merge_duplicates(csvhost_call *calls, uint64_t n, uint64_t *n_out)
+{
+    GUARD({
+        std::vector<SVCall> v; v.reserve(n);
+        for (uint64_t i = 0; i < n; i++) v.push_back(from_pod(calls[i]));
+        mergeDuplicateSVs(v);
+        for (size_t i = 0; i < v.size(); i++) calls[i] = to_pod(v[i]);
+        *n_out = v.size();
+    })
+}
+
+// addSVCall order check: insert the calls one by one, return the resulting order of ids
+int csvhost_add_sv_calls(const csvhost_call *calls, uint64_t n, int64_t *ids_out, uint64_t *n_out)
+{
+    GUARD({
+        std::vector<SVCall> v;
+        for (uint64_t i = 0; i < n; i++) { SVCall c = from_pod(calls[i]); addSVCall(v, c); }
+        for (size_t i = 0; i < v.size(); i++) ids_out[i] = std::stoll(v[i].alt_allele);
+        *n_out = v.size();
+    })
+}
+
+// ---- synthetic shards -------------------------------------------------------------------------
+struct csvhost_synth { SynthShard sh; };
+
+csvhost_synth *csvhost_synth_generate(uint64_t seed, uint32_t chr_len, double depth, int tech, int threads, int with_seq)
+{
+    try {
+        SynthParams p; p.seed = seed; p.chr_len = chr_len; p.depth = depth; p.tech = tech; p.threads = threads; p.with_seq = with_seq;
+        csvhost_synth *h = new csvhost_synth();
+        synth_generate(p, h->sh);
+        return h;
+    } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+void csvhost_synth_view(const csvhost_synth *h, csv_reads *out, uint32_t *depth_len, const uint64_t **seq_off, const uint8_t **seq)
+{
+    *out = h->sh.view(); *depth_len = h->sh.depth_len;
+    if (seq_off) *seq_off = h->sh.seq_off.empty() ? nullptr : h->sh.seq_off.data();
+    if (seq) *seq = h->sh.seq.empty() ? nullptr : h->sh.seq.data();
+}
+void csvhost_synth_free(csvhost_synth *h) { delete h; }
+
+// ---- per-chromosome CIGAR path (SVCaller::processChromosome mirror) ---------------------------
+struct csvhost_chr_stats {
+    uint64_t n_signatures, n_del, n_ins, depth_sum;
+    uint32_t depth_nonzero; int32_t min_pts;
+    double mean_cov, ms_device, ms_host_merge;
+    uint64_t n_calls;
+};
+
+// Runs the whole path on a resident shard and writes the merged calls (POD) + their ALT strings' first
+// bytes are not returned: alt_tag[i] = 0 "<DEL>", 1 "<INS>", 2 literal sequence.
+int csvhost_process_resident_chromosome(csv_ctx *ctx, csv_shard *shard, const uint64_t *seq_off, const uint8_t *seq, double eps,
+                                        double min_pts_pct, csvhost_call *out, uint8_t *alt_tag, uint64_t cap, csvhost_chr_stats *st)
+{
+    GUARD({
+        SVCaller caller(ctx);
+        SeqStore ss; ss.seq_off = seq_off; ss.seq = seq;
+        std::vector<SVCall> calls;
+        ChrStats cs;
+        caller.processResidentChromosome("chr", shard, seq ? &ss : nullptr, eps, min_pts_pct, calls, cs);
+        st->n_signatures = cs.n_signatures; st->n_del = cs.n_del; st->n_ins = cs.n_ins; st->depth_sum = cs.depth_sum;
+        st->depth_nonzero = cs.depth_nonzero; st->min_pts = cs.dbscan_min_pts; st->mean_cov = cs.mean_chr_cov;
+        st->ms_device = cs.ms_device; st->ms_host_merge = cs.ms_host_merge; st->n_calls = calls.size();
+        for (size_t i = 0; i < calls.size() && i < cap; i++) {
+            const SVCall &c = calls[i];
+            csvhost_call p;
+            p.start = c.start; p.end = c.end; p.sv_type = (int32_t)c.sv_type; p.cluster_size = c.cluster_size; p.hmm_likelihood = c.hmm_likelihood;
+            p.id = -1; p.aln_flags = (uint32_t)c.aln_type.to_ulong(); p.genotype = (int32_t)c.genotype; p.cn_state = c.cn_state; p.aln_offset = c.aln_offset;
+            out[i] = p;
+            if (alt_tag) alt_tag[i] = c.alt_allele == "<DEL>" ? 0 : (c.alt_allele == "<INS>" ? 1 : 2);
+        }
+    })
+}
+
+// ---- HMM file + Viterbi seam ------------------------------------------------------------------
+int csvhost_read_chmm(const char *path, csv_hmm *out, int32_t *N)
+{
+    GUARD({
+        CHMM h = ReadCHMM(path);
+        *N = h.N;
+        if (h.N == 6) {
+            for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) out->A[i * 6 + j] = h.A[i][j]; out->pi[i] = h.pi[i]; out->B1_mean[i] = h.B1_mean[i]; out->B1_sd[i] = h.B1_sd[i]; }
+            for (int i = 0; i < 5; i++) { out->B2_mean[i] = h.B2_mean[i]; out->B2_sd[i] = h.B2_sd[i]; }
+            out->B1_uf = h.B1_uf; out->B2_uf = h.B2_uf;
+        }
+    })
+}
+
+}  // extern "C"

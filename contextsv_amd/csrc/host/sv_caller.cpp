@@ -1,0 +1,127 @@
+#include "sv_caller.h"
+
+#include <algorithm>
+#include <chrono>
+#include <stdexcept>
+
+#include "log.h"
+
+namespace {
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void check(csv_ctx *ctx, int rc, const char *what)
+{
+    if (rc != CSV_OK) throw std::runtime_error(std::string(what) + ": " + csvgpu_last_error(ctx));
+}
+}  // namespace
+
+// Field values of the SVCall the reference builds per op (sv_caller.cpp:569-643): INS from I (CIGARINS) or
+// from a soft clip (CIGARCLIP), DEL from D (CIGARDEL); ALT is the inserted sequence only when op_len <= 50
+// (i.e. exactly 50, ambiguity codes RYKMSWBDHV in either case -> N), otherwise "<INS>"; DEL -> "<DEL>".
+SVCall SVCaller::toSVCall(const csv_sig &s, const SeqStore *seq)
+{
+    const uint32_t kind = CSV_SIG_KIND(s);
+    SVEvidenceFlags flags;
+    if (kind == CSV_KIND_DEL) {
+        flags.set((size_t)SVDataType::CIGARDEL);
+        return SVCall(s.start, s.end, SVType::DEL, "<DEL>", flags, Genotype::UNKNOWN, 0.0, 0, 0, 0);
+    }
+    flags.set((size_t)(kind == CSV_KIND_INS ? SVDataType::CIGARINS : SVDataType::CIGARCLIP));
+    const uint32_t op_len = s.end - s.start + 1;
+    std::string alt = "<INS>";
+    if (op_len <= 50) {
+        alt.assign(op_len, 'N');
+        if (seq && seq->seq && seq->seq_off) {
+            static const char nt16[] = "=ACMGRSVTWYHKDBN";              // BAM 4-bit code table (SAM spec §4.2.3)
+            const uint8_t *p = seq->seq + seq->seq_off[s.read];
+            const uint32_t q0 = CSV_SIG_QPOS(s);
+            for (uint32_t j = 0; j < op_len; j++) {
+                const uint32_t q = q0 + j;
+                const char b = nt16[(p[q >> 1] >> ((~q & 1u) << 2)) & 0xf];
+                switch (b) {
+                    case 'R': case 'Y': case 'K': case 'M': case 'S': case 'W': case 'B': case 'D': case 'H': case 'V': alt[j] = 'N'; break;
+                    default: alt[j] = b;
+                }
+            }
+        }
+    }
+    return SVCall(s.start, s.end, SVType::INS, alt, flags, Genotype::UNKNOWN, 0.0, 0, 0, 0);
+}
+
+// mergeTypeWithLabels (sv_object.cpp) specialised to raw CIGAR signatures, keep_noise = false: same bucket order,
+// same std::sort comparator on an index vector, same top-20 % / middle element rule, cluster_size = bucket size.
+void SVCaller::mergeSignaturesWithLabels(const csv_sig *sig, const int32_t *labels, uint64_t n, const SeqStore *seq, std::vector<SVCall> &merged)
+{
+    int32_t max_label = -2;
+    for (uint64_t i = 0; i < n; i++) max_label = std::max(max_label, labels[i]);
+    const size_t n_slots = (size_t)(max_label + 3);
+    std::vector<uint32_t> head(n_slots + 1, 0);
+    for (uint64_t i = 0; i < n; i++) head[(size_t)(labels[i] + 2) + 1]++;
+    for (size_t s = 0; s < n_slots; s++) head[s + 1] += head[s];
+    std::vector<uint32_t> member(n), cur(head.begin(), head.end() - 1);
+    for (uint64_t i = 0; i < n; i++) member[cur[(size_t)(labels[i] + 2)]++] = (uint32_t)i;
+    for (size_t s = 0; s < n_slots; s++) {
+        const size_t sz = head[s + 1] - head[s];
+        if (sz < 2) continue;
+        uint32_t *m = member.data() + head[s];
+        std::sort(m, m + sz, [&](uint32_t a, uint32_t b) { return (sig[a].end - sig[a].start) > (sig[b].end - sig[b].start); });
+        const size_t top = (size_t)std::max(1, (int)(sz * 0.2));
+        SVCall rep = toSVCall(sig[m[top / 2]], seq);
+        rep.cluster_size = (int)sz;
+        merged.push_back(rep);
+    }
+}
+
+void SVCaller::processResidentChromosome(const std::string &chr, csv_shard *shard, const SeqStore *seq, double eps, double pct,
+                                         std::vector<SVCall> &chr_sv_calls, ChrStats &st)
+{
+    const double t0 = now_ms();
+    csv_chr_result res;
+    check(ctx, csvgpu_chr_pipeline_dev(ctx, shard, (uint32_t)min_oplen, (uint8_t)min_mapq, eps, pct, &res), "processChromosome");
+    st.n_signatures = res.n_sig; st.n_del = res.n_del; st.n_ins = res.n_ins;
+    st.depth_sum = res.depth_sum; st.depth_nonzero = res.depth_nonzero; st.mean_chr_cov = res.mean_cov; st.dbscan_min_pts = res.min_pts;
+    if (pct > 0.0)
+        printMessage(chr + ": Mean chr. cov.: " + std::to_string(res.mean_cov) + " (DBSCAN min. pts.= " + std::to_string(res.min_pts) +
+                     ", min. pts. pct.= " + std::to_string(pct) + ")");
+    std::vector<csv_sig> sig(res.n_sig);
+    std::vector<int32_t> lab(res.n_sig);
+    // sig_del/sig_ins and label_del/label_ins are adjacent in the shard's scratch: one copy each
+    check(ctx, csvgpu_download(ctx, sig.data(), res.sig_del, res.n_sig * sizeof(csv_sig)), "download signatures");
+    check(ctx, csvgpu_download(ctx, lab.data(), res.label_del, res.n_sig * sizeof(int32_t)), "download labels");
+    const double t1 = now_ms();
+
+    // mergeSVs(chr_sv_calls, eps, min_pts, keep_noise=false) with the labels already computed on device.
+    // Every CIGAR call has hmm_likelihood == 0, so only the length-ranked branch of the representative choice
+    // can run (sv_object.cpp:187-244 of the reference); it is evaluated on the 16-byte signatures and an SVCall
+    // (with its strings) is materialised for the chosen member only.
+    chr_sv_calls.clear();
+    printMessage(chr + ": Merging CIGAR...");
+    if (res.n_sig < 2) {                                   // mergeSVs returns early (:49-51)
+        for (uint64_t i = 0; i < res.n_sig; i++) chr_sv_calls.push_back(toSVCall(sig[i], seq));
+    } else {
+        const uint64_t type_n[2] = {res.n_del, res.n_ins};
+        uint64_t base = 0;
+        for (int t = 0; t < 2; t++) {
+            if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) chr_sv_calls.push_back(toSVCall(sig[base + i], seq));
+            else mergeSignaturesWithLabels(sig.data() + base, lab.data() + base, type_n[t], seq, chr_sv_calls);
+            base += type_n[t];
+        }
+    }
+    st.ms_device = t1 - t0; st.ms_host_merge = now_ms() - t1;
+    printMessage(chr + ": Found " + std::to_string(getSVCount(chr_sv_calls)) + " SV candidates in the CIGAR string");
+}
+
+void SVCaller::processChromosome(const std::string &chr, const csv_reads &reads, const SeqStore *seq, uint32_t depth_len, double eps,
+                                 double pct, std::vector<SVCall> &chr_sv_calls, ChrStats &stats, csv_shard **keep_shard)
+{
+    printMessage(chr + ": CIGAR SVs...");
+    csv_shard *sh = csvgpu_shard_upload(ctx, &reads, depth_len);
+    if (!sh) throw std::runtime_error(std::string("processChromosome: ") + csvgpu_last_error(ctx));
+    try {
+        processResidentChromosome(chr, sh, seq, eps, pct, chr_sv_calls, stats);
+    } catch (...) {
+        csvgpu_shard_free(ctx, sh);
+        throw;
+    }
+    if (keep_shard) *keep_shard = sh; else csvgpu_shard_free(ctx, sh);
+}

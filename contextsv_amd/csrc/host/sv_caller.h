@@ -1,0 +1,53 @@
+// sv_caller.h — host mirror of the per-chromosome CIGAR path of the reference's SVCaller
+// (src/sv_caller.cpp:506-537 findCIGARSVs, :539-661 processCIGARRecord, :692-745 processChromosome) and of
+// the depth pass in front of it (src/cnv_caller.cpp:415-556), working on a decoded struct-of-arrays
+// shard instead of an htslib iterator. All per-read and per-signature work runs on the GPU behind the
+// C-ABI; the host keeps only the order-defining representative choice (mergeSVs) and the string fields.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/csvgpu.h"
+#include "sv_object.h"
+
+// 4-bit packed read sequences (BAM encoding, two bases per byte, high nibble first); optional.
+struct SeqStore {
+    const uint64_t *seq_off = nullptr;   // [n_reads+1] byte offset of each read's packed sequence
+    const uint8_t *seq = nullptr;
+};
+
+struct ChrStats {
+    uint64_t n_signatures = 0, n_del = 0, n_ins = 0;
+    uint64_t depth_sum = 0;
+    uint32_t depth_nonzero = 0;
+    double mean_chr_cov = 0.0;
+    int dbscan_min_pts = 0;
+    double ms_device = 0.0, ms_host_merge = 0.0;
+};
+
+class SVCaller {
+public:
+    explicit SVCaller(csv_ctx *ctx) : ctx(ctx) {}
+    int min_mapq = 20;       // sv_caller.h:72 of the reference
+    int min_oplen = 50;      // sv_caller.cpp:566
+
+    // Depth pass + CIGAR pass + CIGAR merge of one chromosome. `reads` are host arrays; they are uploaded,
+    // the device pipeline runs, labels and signatures come back, and mergeSVs' representative choice runs
+    // here. On return chr_sv_calls == the reference's vector after mergeSVs(chr_sv_calls, eps, min_pts, false).
+    // If keep_shard != nullptr the resident shard (depth map etc.) is handed to the caller, who frees it.
+    void processChromosome(const std::string &chr, const csv_reads &reads, const SeqStore *seq, uint32_t depth_len,
+                           double dbscan_epsilon, double dbscan_min_pts_pct, std::vector<SVCall> &chr_sv_calls,
+                           ChrStats &stats, csv_shard **keep_shard = nullptr);
+
+    // Same, for a shard that is already resident (benchmark / multi-pass use).
+    void processResidentChromosome(const std::string &chr, csv_shard *shard, const SeqStore *seq, double dbscan_epsilon,
+                                   double dbscan_min_pts_pct, std::vector<SVCall> &chr_sv_calls, ChrStats &stats);
+
+    // signature -> SVCall with the reference's field values (sv_caller.cpp:569-643)
+    static SVCall toSVCall(const csv_sig &s, const SeqStore *seq);
+    static void mergeSignaturesWithLabels(const csv_sig *sig, const int32_t *labels, uint64_t n, const SeqStore *seq, std::vector<SVCall> &merged);
+
+private:
+    csv_ctx *ctx;
+};

@@ -21,7 +21,6 @@ namespace csv {
 constexpr int D1_THREADS = 256;
 constexpr int D1_WAVES = D1_THREADS / WAVE;
 constexpr int D1_MAX = (int)DBSCAN1D_MAX_SEG;      // 512
-constexpr int D1_PER_LANE = D1_MAX / WAVE;         // 8
 constexpr uint32_t D1_NONE = 0xffffffffu;
 
 struct D1Lds {

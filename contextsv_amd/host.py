@@ -1,0 +1,160 @@
+"""ctypes bindings of the C++ host mirror (csrc/host/ -> lib/libcontextsv_host.so): mergeSVs and friends,
+the per-chromosome SVCaller path, the HMM file parser and the synthetic shard generator. Plumbing only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .context import Context, Reads, Shard
+
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcontextsv_host.so")
+
+CALL_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("sv_type", "<i4"), ("cluster_size", "<i4"), ("hmm_likelihood", "<f8"),
+                       ("id", "<i8"), ("aln_flags", "<u4"), ("genotype", "<i4"), ("cn_state", "<i4"), ("aln_offset", "<i4")])
+
+
+class chr_stats(C.Structure):
+    _fields_ = [("n_signatures", C.c_uint64), ("n_del", C.c_uint64), ("n_ins", C.c_uint64), ("depth_sum", C.c_uint64),
+                ("depth_nonzero", C.c_uint32), ("min_pts", C.c_int32), ("mean_cov", C.c_double), ("ms_device", C.c_double),
+                ("ms_host_merge", C.c_double), ("n_calls", C.c_uint64)]
+
+
+_P = C.c_void_p
+_hlib = None
+
+
+def load() -> C.CDLL:
+    global _hlib
+    if _hlib is not None:
+        return _hlib
+    _lib.load()          # libcsvgpu.so first (the host mirror links against it)
+    if not os.path.exists(HOST_LIB_PATH):
+        raise RuntimeError(f"host mirror not built: {HOST_LIB_PATH} is missing — run __graft_entry__.build()")
+    lib = C.CDLL(HOST_LIB_PATH)
+    lib.csvhost_last_error.restype = C.c_char_p
+    lib.csvhost_set_context.argtypes = [_P]
+    lib.csvhost_set_quiet.argtypes = [C.c_int]
+    lib.csvhost_merge_svs.argtypes = [_P, C.c_uint64, C.c_double, C.c_int32, C.c_int, _P, C.POINTER(C.c_uint64)]
+    lib.csvhost_merge_type_with_labels.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.POINTER(C.c_uint64)]
+    lib.csvhost_merge_duplicates.argtypes = [_P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.csvhost_add_sv_calls.argtypes = [_P, C.c_uint64, _P, C.POINTER(C.c_uint64)]
+    lib.csvhost_synth_generate.restype = _P
+    lib.csvhost_synth_generate.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int]
+    lib.csvhost_synth_view.argtypes = [_P, C.POINTER(_lib.csv_reads), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P)]
+    lib.csvhost_synth_free.argtypes = [_P]
+    lib.csvhost_process_resident_chromosome.argtypes = [_P, _P, _P, _P, C.c_double, C.c_double, _P, _P, C.c_uint64, C.POINTER(chr_stats)]
+    lib.csvhost_read_chmm.argtypes = [C.c_char_p, C.POINTER(_lib.csv_hmm), C.POINTER(C.c_int32)]
+    lib.csvhost_set_quiet(1)
+    _hlib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError((load().csvhost_last_error() or b"host error").decode())
+
+
+def set_context(ctx: Context):
+    load().csvhost_set_context(ctx.h)
+
+
+def make_calls(start, end, sv_type, cluster_size=None, hmm_likelihood=None) -> np.ndarray:
+    n = len(start)
+    c = np.zeros(n, CALL_DTYPE)
+    c["start"], c["end"], c["sv_type"] = start, end, sv_type
+    c["cluster_size"] = 0 if cluster_size is None else cluster_size
+    c["hmm_likelihood"] = 0.0 if hmm_likelihood is None else hmm_likelihood
+    c["id"] = np.arange(n)
+    c["genotype"] = 3
+    return c
+
+
+def merge_svs(calls: np.ndarray, eps: float, min_pts: int, keep_noise: bool) -> np.ndarray:
+    """mergeSVs (host mirror; DBSCAN labels from the GPU). Needs set_context()."""
+    calls = np.ascontiguousarray(calls, CALL_DTYPE)
+    out = np.zeros(max(len(calls), 1), CALL_DTYPE)
+    n = C.c_uint64(0)
+    _check(load().csvhost_merge_svs(calls.ctypes.data, len(calls), eps, min_pts, int(keep_noise), out.ctypes.data, C.byref(n)))
+    return out[: n.value].copy()
+
+
+def merge_type_with_labels(calls: np.ndarray, labels: np.ndarray, keep_noise: bool) -> np.ndarray:
+    calls = np.ascontiguousarray(calls, CALL_DTYPE)
+    labels = np.ascontiguousarray(labels, np.int32)
+    out = np.zeros(max(len(calls), 1), CALL_DTYPE)
+    n = C.c_uint64(0)
+    _check(load().csvhost_merge_type_with_labels(calls.ctypes.data, labels.ctypes.data, len(calls), int(keep_noise), out.ctypes.data, C.byref(n)))
+    return out[: n.value].copy()
+
+
+def merge_duplicates(calls: np.ndarray) -> np.ndarray:
+    calls = np.ascontiguousarray(calls, CALL_DTYPE).copy()
+    n = C.c_uint64(0)
+    _check(load().csvhost_merge_duplicates(calls.ctypes.data, len(calls), C.byref(n)))
+    return calls[: n.value].copy()
+
+
+def add_sv_calls_order(calls: np.ndarray) -> np.ndarray:
+    calls = np.ascontiguousarray(calls, CALL_DTYPE)
+    ids = np.zeros(max(len(calls), 1), np.int64)
+    n = C.c_uint64(0)
+    _check(load().csvhost_add_sv_calls(calls.ctypes.data, len(calls), ids.ctypes.data, C.byref(n)))
+    return ids[: n.value].copy()
+
+
+class SynthShard:
+    """A generated shard living in the host library's memory; `reads` are zero-copy numpy views."""
+
+    def __init__(self, seed: int, chr_len: int, depth: float, tech: int = 0, threads: int = 8, with_seq: bool = False):
+        lib = load()
+        self.h = lib.csvhost_synth_generate(seed, chr_len, depth, tech, threads, int(with_seq))
+        if not self.h:
+            raise RuntimeError((lib.csvhost_last_error() or b"").decode())
+        r = _lib.csv_reads()
+        dl = C.c_uint32(0)
+        so, sq = _P(), _P()
+        lib.csvhost_synth_view(self.h, C.byref(r), C.byref(dl), C.byref(so), C.byref(sq))
+        n, m = r.n_reads, r.n_cigar
+
+        def view(p, count, dtype):
+            if not p or count == 0:
+                return np.zeros(0, dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p)
+            return np.frombuffer(buf, dtype=dtype)
+
+        self.depth_len = dl.value
+        self.reads = Reads.__new__(Reads)
+        self.reads.pos = view(r.pos, n, np.int32)
+        self.reads.flag = view(r.flag, n, np.uint16)
+        self.reads.mapq = view(r.mapq, n, np.uint8)
+        self.reads.tid = view(r.tid, n, np.int32)
+        self.reads.cigar_off = view(r.cigar_off, n + 1, np.uint64)
+        self.reads.cigar = view(r.cigar, m, np.uint32)
+        self.seq_off_ptr, self.seq_ptr = so.value, sq.value
+
+    def free(self):
+        if self.h:
+            self.reads = None
+            load().csvhost_synth_free(self.h)
+            self.h = None
+
+
+def process_resident_chromosome(ctx: Context, shard: Shard, eps: float, min_pts_pct: float, seq_off_ptr=None, seq_ptr=None, capacity: int = 1 << 20):
+    """SVCaller::processChromosome mirror on a resident shard -> (merged calls, alt tags, stats)."""
+    out = np.zeros(capacity, CALL_DTYPE)
+    tag = np.zeros(capacity, np.uint8)
+    st = chr_stats()
+    _check(load().csvhost_process_resident_chromosome(ctx.h, shard.h, seq_off_ptr, seq_ptr, eps, min_pts_pct, out.ctypes.data, tag.ctypes.data,
+                                                      capacity, C.byref(st)))
+    n = min(st.n_calls, capacity)
+    return out[:n].copy(), tag[:n].copy(), st
+
+
+def read_chmm(path: str):
+    h = _lib.csv_hmm()
+    n = C.c_int32(0)
+    _check(load().csvhost_read_chmm(path.encode(), C.byref(h), C.byref(n)))
+    return h, n.value

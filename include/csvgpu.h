@@ -223,6 +223,10 @@ typedef struct csv_chr_result {
 int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, uint8_t min_mapq,
                             double eps, double min_pts_pct, csv_chr_result *result);
 
+/* Copy `bytes` from device memory returned by this library (csv_chr_result pointers) to host memory;
+ * synchronous with respect to the context's stream. For host code above the ABI that does not link HIP. */
+int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
 /* Device-pointer twins of the clustering / HMM entry points (same semantics as above). */
 int csvgpu_dbscan_iv_dev(csv_ctx *ctx, const uint32_t *d_start, const uint32_t *d_end, uint64_t n,
                          double eps, int32_t min_pts, int32_t *d_labels);
