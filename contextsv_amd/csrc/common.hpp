@@ -58,6 +58,7 @@ struct csv_shard {
     bool      owned = false;       // true: arrays hipMalloc'd by csvgpu_shard_upload
     // per-read side arrays + per-chromosome outputs (device, owned by the shard)
     int32_t  *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr, *pmax_end = nullptr;
+    uint32_t *ckpt = nullptr;      // per-256-word reference checkpoints (scan -> depth)
     uint32_t *depth = nullptr;
     csv_sig  *sig_raw = nullptr;   uint64_t sig_cap = 0;
     csv_sig  *sig_sorted = nullptr;
@@ -113,14 +114,16 @@ static inline int bits_of(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } r
 // scan.hip
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
-                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, ScanCounters *cnt);
+                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt);
 // depth.hip
 void launch_prefix_max(hipStream_t s, const int32_t *in, int32_t *out, uint64_t n, void *tmp /* >= 4 KiB + n/1024*4 */);
 size_t prefix_max_tmp_bytes(uint64_t n);
 // ord == nullptr: reads are coordinate-sorted and pos_s == d.pos; otherwise pos_s / pmax_end are in ord order.
+// ckpt: reference offset of the owning read at every 256-word CIGAR boundary (written by launch_cigar_scan).
 void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *pos_s,
-                        const int32_t *ref_end, const int32_t *pmax_end, uint32_t depth_len, uint32_t *depth,
-                        ScanCounters *cnt);
+                        const int32_t *ref_end, const int32_t *pmax_end, const uint32_t *ckpt, uint32_t depth_len,
+                        uint32_t *depth, ScanCounters *cnt);
+static inline size_t ckpt_bytes(uint64_t n_cigar) { return ((n_cigar >> 8) + 2) * sizeof(uint32_t); }
 void launch_min_pts(hipStream_t s, ScanCounters *cnt, double min_pts_pct);
 // sort.hip
 size_t radix_sort_tmp_bytes(uint64_t n);

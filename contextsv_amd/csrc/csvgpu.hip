@@ -88,6 +88,7 @@ static void fold_timers(csv_ctx *ctx)
 struct DevReads {
     csv_reads d;
     int32_t *ref_end, *q_start, *q_end;
+    uint32_t *ckpt;
     ScanCounters *cnt;
 };
 
@@ -95,7 +96,7 @@ static size_t reads_bytes(const csv_reads *r)
 {
     const uint64_t n = r->n_reads, m = r->n_cigar;
     return align_up(n * 4, 256) + align_up(n * 2, 256) + align_up(n, 256) + align_up((n + 1) * 8, 256) + align_up(m * 4 + 16, 256) +
-           3 * align_up(n * 4, 256) + 256;
+           3 * align_up(n * 4, 256) + align_up(ckpt_bytes(m), 256) + 512;
 }
 
 // copy a host shard into the arena; returns device views
@@ -112,7 +113,8 @@ static int stage_reads(csv_ctx *ctx, const csv_reads *r, DevReads &o)
     o.q_start = (int32_t *)arena_alloc(a, n * 4);
     o.q_end = (int32_t *)arena_alloc(a, n * 4);
     o.cnt = (ScanCounters *)arena_alloc(a, sizeof(ScanCounters));
-    if (!pos || !flag || !mapq || !coff || !cig || !o.ref_end || !o.q_start || !o.q_end || !o.cnt) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    o.ckpt = (uint32_t *)arena_alloc(a, ckpt_bytes(m));
+    if (!o.ckpt || !pos || !flag || !mapq || !coff || !cig || !o.ref_end || !o.q_start || !o.q_end || !o.cnt) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     hipStream_t s = ctx->stream;
     if (n) {
         CSV_HIP(ctx, hipMemcpyAsync(pos, r->pos, n * 4, hipMemcpyHostToDevice, s));
@@ -179,7 +181,7 @@ static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, u
 }
 
 // depth chain on device arrays. pmax / ord scratch comes from `a`.
-static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t *ref_end, bool unsorted, uint32_t depth_len,
+static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t *ref_end, const uint32_t *ckpt, bool unsorted, uint32_t depth_len,
                        uint32_t *depth, ScanCounters *cnt)
 {
     const uint64_t n = d.n_reads;
@@ -207,7 +209,7 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
         ord = perm; pos_s = (const int32_t *)pos_g; end_s = (const int32_t *)end_g;
     }
     launch_prefix_max(ctx->stream, end_s, pmax, n, ptmp);
-    launch_depth_tiles(ctx->stream, d, ord, pos_s, ref_end, pmax, depth_len, depth, cnt);
+    launch_depth_tiles(ctx->stream, d, ord, pos_s, ref_end, pmax, ckpt, depth_len, depth, cnt);
     return CSV_OK;
 }
 static size_t depth_chain_bytes(uint64_t n)
@@ -347,7 +349,7 @@ int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, 
     if (!sig_raw) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
-        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, min_oplen, min_mapq, 1, sig_raw, cap, dr.ref_end, dr.q_start, dr.q_end, dr.cnt);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, min_oplen, min_mapq, 1, sig_raw, cap, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt);
     }
     ScanCounters h;
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
@@ -376,7 +378,7 @@ int csvgpu_aln_intervals(csv_ctx *ctx, const csv_reads *reads, int32_t *ref_end,
     if ((rc = stage_reads(ctx, reads, dr))) return rc;
     {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
-        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, 0, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.cnt);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, 0, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt);
     }
     const uint64_t n = reads->n_reads;
     if (n) {
@@ -400,12 +402,12 @@ int csvgpu_depth(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, uint3
     if (!d_depth) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
-        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.cnt);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt);
     }
     ScanCounters h;
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
     if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(reads->n_reads)))) return rc;
-    if ((rc = depth_chain(ctx, ctx->work, dr.d, dr.ref_end, h.unsorted != 0, depth_len, d_depth, dr.cnt))) return rc;
+    if ((rc = depth_chain(ctx, ctx->work, dr.d, dr.ref_end, dr.ckpt, h.unsorted != 0, depth_len, d_depth, dr.cnt))) return rc;
     if (depth && depth_len) CSV_HIP(ctx, hipMemcpyAsync(depth, d_depth, (size_t)depth_len * 4, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
     if (sum) *sum = h.depth_sum;
@@ -636,6 +638,7 @@ static void shard_release(csv_shard *sh)
         (void)hipFree((void *)sh->d.cigar_off); (void)hipFree((void *)sh->d.cigar);
     }
     (void)hipFree(sh->ref_end); (void)hipFree(sh->q_start); (void)hipFree(sh->q_end);
+    (void)hipFree(sh->ckpt);
     (void)hipFree(sh->depth); (void)hipFree(sh->sig_raw); (void)hipFree(sh->scratch); (void)hipFree(sh->counters);
     delete sh;
 }
@@ -649,6 +652,7 @@ static csv_shard *shard_common(csv_ctx *ctx, csv_shard *sh)
     ok &= hipMalloc((void **)&sh->q_end, n * 4 + 16) == hipSuccess;
     ok &= hipMalloc((void **)&sh->depth, (size_t)sh->depth_len * 4 + 16) == hipSuccess;
     ok &= hipMalloc((void **)&sh->counters, 256) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->ckpt, ckpt_bytes(sh->d.n_cigar)) == hipSuccess;
     sh->sig_cap = std::max<uint64_t>(1u << 18, n * 2);
     ok &= hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); ctx->err = "hipMalloc failed (shard)"; shard_release(sh); return nullptr; }
@@ -728,7 +732,7 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
         {
             TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
             launch_cigar_scan(s, ctx->n_cu, sh->d, sh->depth_len, min_oplen, min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                              sh->q_start, sh->q_end, cnt);
+                              sh->q_start, sh->q_end, sh->ckpt, cnt);
         }
         if ((rc = read_counters(ctx, cnt, h))) return rc;                 // the one mid-pipeline host sync
         if (h.n_sig <= sh->sig_cap) break;
@@ -759,7 +763,7 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
 
     // depth map + mean coverage + min_pts (device scalar)
     if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads)))) return rc;
-    if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, h.unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
+    if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, h.unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
     launch_min_pts(s, cnt, min_pts_pct);
 
     // ordering: DEL calls then INS calls, each in chr_sv_calls order

@@ -5,24 +5,28 @@
 //
 // The reference does ~30 x chromosome-length scalar increments. A read-owner GPU version would
 // need two scattered global atomics per M-run (~1.5e8 per chr22 at 30x, far below the HBM rate), so
-// the ownership is turned around: one workgroup owns one 16 Ki-position tile of the chromosome,
-// keeps the tile's DIFFERENCE array in LDS (64 KiB), finds the reads that overlap the tile by
-// binary search (reads are coordinate-sorted; a prefix maximum of the read ends bounds the search
-// on the left), walks their CIGARs with the same 16-byte/lane wave scan as scan.hip, applies
-// +1/-1 with LDS atomics, and finally scans the tile in LDS and writes depth once, coalesced,
-// 16 B per lane, while accumulating sum and non-zero count. No global atomics on the depth array,
-// no memset, no separate scan pass: HBM traffic = CIGAR stream re-read (x ~1.7 for 12 kb reads on a
-// 16 kb tile) + 4 B/base written.
+// the ownership is turned around: one workgroup owns one 8 Ki-position tile of the chromosome and
+// keeps the tile's DIFFERENCE array in LDS (32 KiB -> 4 workgroups, 32 waves per CU). It finds the
+// reads that overlap the tile by binary search (reads are coordinate-sorted; a prefix maximum of the
+// read ends bounds the search on the left); each wave takes reads from that range, skips the ones
+// that end left of the tile, jumps into the CIGAR at the last 256-word checkpoint left of the tile
+// (scan.hip records the reference offset of a read at every 256-word boundary; the checkpoints of a
+// read are fetched by all lanes in one load), walks 1 KiB chunks with the same 16-byte/lane wave scan
+// as scan.hip with the next chunk and the next read's metadata already in flight, applies +1/-1 with
+// LDS atomics, and stops at the tile's right edge. Finally the tile is scanned in LDS and depth is
+// written once, coalesced, 16 B per lane, while sum and non-zero count are accumulated. No global
+// atomics on the depth array, no memset, no separate scan pass. HBM traffic = CIGAR stream x (1 +
+// ~1 chunk per (tile, read) pair) + 4 B/base written.
 #include "../common.hpp"
 #include "../devutil.hpp"
 
 namespace csv {
 
-constexpr int DEPTH_TILE = 16384;
+constexpr int DEPTH_TILE = 8192;
 constexpr int DEPTH_THREADS = 512;
 constexpr int DEPTH_WAVES = DEPTH_THREADS / WAVE;          // 8
-constexpr int DEPTH_PER_WAVE = DEPTH_TILE / DEPTH_WAVES;   // 2048 entries scanned per wave
-constexpr int DEPTH_ROUNDS = DEPTH_PER_WAVE / (4 * WAVE);  // 8 rounds of 256
+constexpr int DEPTH_PER_WAVE = DEPTH_TILE / DEPTH_WAVES;   // entries scanned per wave
+constexpr int DEPTH_ROUNDS = DEPTH_PER_WAVE / (4 * WAVE);  // rounds of 256 entries
 
 // ------------------------------------------------------------------------------- prefix max
 constexpr int PM_THREADS = 256;
@@ -112,13 +116,35 @@ void launch_prefix_max(hipStream_t s, const int32_t *in, int32_t *out, uint64_t 
 }
 
 // ------------------------------------------------------------------------------- depth tiles
-__global__ __launch_bounds__(DEPTH_THREADS) void depth_tile_kernel(
+struct ReadMd {            // per-read metadata a wave needs, loaded one read ahead of use
+    uint64_t c0, c1;
+    uint32_t p1;           // 1-based first reference position (cnv_caller.cpp:498)
+    uint32_t ok;           // overlaps the tile and passes the depth filter
+};
+
+__device__ __forceinline__ ReadMd depth_load_md(uint64_t kk, uint64_t k_hi, const uint32_t *__restrict__ ord,
+                                                const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
+                                                const uint64_t *__restrict__ cigar_off, const int32_t *__restrict__ ref_end, uint64_t T0)
+{
+    ReadMd m; m.c0 = 0; m.c1 = 0; m.p1 = 0; m.ok = 0;
+    if (kk < k_hi) {
+        const uint64_t r = ord ? (uint64_t)ord[kk] : kk;
+        m.c0 = cigar_off[r]; m.c1 = cigar_off[r + 1];
+        m.p1 = (uint32_t)pos[r] + 1u;
+        const uint32_t fl = flag[r];
+        m.ok = ((int64_t)ref_end[r] >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP));   // cnv_caller.cpp:491-495
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int vec_ok, int dvec_ok,
     const uint32_t *__restrict__ ord,        // nullptr: reads already sorted by pos; else pos_s/pmax_end are in ord order
     const int32_t *__restrict__ pos_s,       // positions in sorted order (== pos when ord == nullptr)
-    const int32_t *__restrict__ ref_end, const int32_t *__restrict__ pmax_end, uint32_t depth_len,
-    uint32_t *__restrict__ depth, ScanCounters *__restrict__ cnt)
+    const int32_t *__restrict__ ref_end, const int32_t *__restrict__ pmax_end,
+    const uint32_t *__restrict__ ckpt,       // reference offset of the owning read at every 256-word boundary (scan.hip)
+    uint32_t depth_len, uint32_t *__restrict__ depth, ScanCounters *__restrict__ cnt)
 {
     __shared__ uint32_t diff[DEPTH_TILE + 4];
     __shared__ uint32_t wave_tot[DEPTH_WAVES];
@@ -145,25 +171,48 @@ __global__ __launch_bounds__(DEPTH_THREADS) void depth_tile_kernel(
     __syncthreads();
     const uint64_t k_lo = range_s[0], k_hi = range_s[1];
 
+    ReadMd md = depth_load_md(k_lo + wave, k_hi, ord, pos, flag, cigar_off, ref_end, T0);
     for (uint64_t kk = k_lo + wave; kk < k_hi; kk += DEPTH_WAVES) {
-        const uint64_t r = ord ? (uint64_t)ord[kk] : kk;
-        if ((int64_t)ref_end[r] < (int64_t)T0) continue;
-        const uint32_t fl = flag[r];
-        if (fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) continue;          // cnv_caller.cpp:491-495
-        const uint64_t c0 = cigar_off[r], c1 = cigar_off[r + 1];
-        const uint64_t p1 = (uint64_t)(uint32_t)pos[r] + 1;                     // 1-based first reference position (:498)
+        const ReadMd cur = md;
+        md = depth_load_md(kk + DEPTH_WAVES, k_hi, ord, pos, flag, cigar_off, ref_end, T0);   // next read's metadata in flight
+        if (!cur.ok || cur.c1 <= cur.c0) continue;
+        const uint64_t c0 = cur.c0, c1 = cur.c1;
+        const uint64_t p1 = cur.p1;
+        // skip the chunks that lie left of the tile: all lanes fetch the read's checkpoints at once
+        uint64_t chunk = c0 & ~255ull;
         uint64_t ref_carry = 0;
-        const uint64_t base = c0 & ~3ull;
-        for (uint64_t chunk = base; chunk < c1; chunk += 4 * WAVE) {
-            if (p1 + ref_carry >= T1) break;                                   // rest of the read lies right of the tile
+        {
+            const uint64_t g0 = c0 >> 8, g1 = (c1 - 1) >> 8;
+            for (uint64_t gb = g0 + 1; gb <= g1; gb += WAVE) {
+                const uint64_t g = gb + lane;
+                uint32_t ck = 0; bool left = false;
+                if (g <= g1) { ck = ckpt[g]; left = p1 + ck <= T0; }
+                const uint64_t m = __ballot(left);
+                const int n_left = __popcll(m);                 // checkpoints are non-decreasing: `left` is a prefix
+                if (n_left) { chunk = (gb + n_left - 1) << 8; ref_carry = __shfl(ck, n_left - 1, 64); }
+                if (n_left < WAVE) break;
+            }
+        }
+        uint32_t w[4], wn[4];
+        {
             const uint64_t idx = chunk + (uint64_t)lane * 4;
-            uint32_t w[4];
-            if (vec_ok && idx + 4 <= n_cigar) {
-                uint4 v = *reinterpret_cast<const uint4 *>(cigar + idx);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
+            if (vec_ok && idx + 4 <= n_cigar) { const uint4 v = *reinterpret_cast<const uint4 *>(cigar + idx); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) w[k] = (idx + k < n_cigar) ? cigar[idx + k] : (uint32_t)OP_P;
+            }
+        }
+        for (; chunk < c1; chunk += 4 * WAVE) {
+            if (p1 + ref_carry >= T1) break;                                   // rest of the read lies right of the tile
+            const uint64_t idx = chunk + (uint64_t)lane * 4;
+            const bool more = chunk + 4 * WAVE < c1;
+            if (more) {                                                        // prefetch the next 1 KiB
+                const uint64_t idn = idx + 4 * WAVE;
+                if (vec_ok && idn + 4 <= n_cigar) { const uint4 v = *reinterpret_cast<const uint4 *>(cigar + idn); wn[0] = v.x; wn[1] = v.y; wn[2] = v.z; wn[3] = v.w; }
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) wn[k] = (idn + k < n_cigar) ? cigar[idn + k] : (uint32_t)OP_P;
+                }
             }
             uint32_t len[4], rl[4], aln = 0, lane_ref = 0;
 #pragma unroll
@@ -189,11 +238,15 @@ __global__ __launch_bounds__(DEPTH_THREADS) void depth_tile_kernel(
                 a1 += rl[k];
             }
             ref_carry += __shfl(incl, 63, 64);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = wn[k];
+            }
         }
     }
     __syncthreads();
 
-    // scan the difference array: wave w owns entries [w*2048, (w+1)*2048)
+    // scan the difference array: wave w owns entries [w*DEPTH_PER_WAVE, (w+1)*DEPTH_PER_WAVE)
     const int w_base = wave * DEPTH_PER_WAVE;
     uint32_t tot = 0;
 #pragma unroll
@@ -246,15 +299,15 @@ __global__ __launch_bounds__(DEPTH_THREADS) void depth_tile_kernel(
 }
 
 void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *pos_s,
-                        const int32_t *ref_end, const int32_t *pmax_end, uint32_t depth_len, uint32_t *depth,
-                        ScanCounters *cnt)
+                        const int32_t *ref_end, const int32_t *pmax_end, const uint32_t *ckpt, uint32_t depth_len,
+                        uint32_t *depth, ScanCounters *cnt)
 {
     if (depth_len == 0) return;
     const unsigned tiles = (unsigned)(((uint64_t)depth_len + DEPTH_TILE - 1) / DEPTH_TILE);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     const int dvec_ok = (((uintptr_t)depth) & 15u) == 0;
     hipLaunchKernelGGL(depth_tile_kernel, dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
-                       d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, pos_s, ref_end, pmax_end, depth_len, depth, cnt);
+                       d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, pos_s, ref_end, pmax_end, ckpt, depth_len, depth, cnt);
 }
 
 // min_pts = (int)ceil(mean_cov * pct), or 5 when pct <= 0 (sv_caller.cpp:723-728); mean = sum / #non-zero

@@ -4,7 +4,7 @@
 // getAlignmentReadPositions + bam_endpos (sv_caller.cpp:663-690) for one shard of reads.
 //
 // One 64-lane wave owns one read at a time. Each lane takes 4 consecutive packed CIGAR words
-// (one 16-byte load, 1 KiB per wave instruction, 16-byte aligned by starting at cigar_off & ~3 and
+// (one 16-byte load, 1 KiB per wave instruction, aligned by starting at cigar_off & ~255 and
 // masking the words that belong to the neighbouring reads), a wave prefix sum turns op lengths
 // into reference / query cursors, and ops with len >= min_oplen of kind I / S / D become 16-byte
 // signatures. Signatures are rare (~1e-3 of ops) so they are staged in a per-workgroup LDS buffer
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
     const uint8_t *__restrict__ mapq, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
     int vec_ok, uint32_t depth_len, uint32_t min_oplen, uint32_t min_mapq, int emit,
     csv_sig *__restrict__ sig_out, uint64_t sig_cap, int32_t *__restrict__ ref_end, int32_t *__restrict__ q_start,
-    int32_t *__restrict__ q_end, ScanCounters *__restrict__ cnt)
+    int32_t *__restrict__ q_end, uint32_t *__restrict__ ckpt, ScanCounters *__restrict__ cnt)
 {
     __shared__ csv_sig buf[SIG_BUF];
     __shared__ uint32_t buf_n, blk_max_start, blk_max_len, blk_n_del;
@@ -75,10 +75,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
         uint32_t skip_carry = 0;     // lengths of soft clips skipped by the `continue` at sv_caller.cpp:602-604
         int32_t  qs = -1;            // query_start
 
-        const uint64_t base = c0 & ~3ull;
+        // chunks are aligned to 256 words (1 KiB) globally, so that a chunk boundary is a checkpoint slot
+        const uint64_t base = c0 & ~255ull;
         Chunk cur = load_chunk(cigar, base + (uint64_t)lane * 4, n_cigar, vec_ok);
         for (uint64_t chunk = base; chunk < c1; chunk += 4 * WAVE) {
             const uint64_t idx = chunk + (uint64_t)lane * 4;
+            if (lane == 0 && chunk > c0) ckpt[chunk >> 8] = ref_carry;     // reference offset of this read at word `chunk` (depth.hip)
             Chunk nxt;
             const bool more = chunk + 4 * WAVE < c1;
             if (more) nxt = load_chunk(cigar, idx + 4 * WAVE, n_cigar, vec_ok);   // prefetch next 1 KiB
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
 
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
-                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, ScanCounters *cnt)
+                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt)
 {
     if (d.n_reads == 0) return;
     uint64_t want = (d.n_reads + SCAN_WAVES - 1) / SCAN_WAVES;
@@ -236,7 +238,7 @@ void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t dep
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     hipLaunchKernelGGL(cigar_scan_kernel, dim3(grid), dim3(SCAN_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
                        d.mapq, d.cigar_off, d.cigar, vec_ok, depth_len, min_oplen, min_mapq, emit, sig_out, sig_cap,
-                       ref_end, q_start, q_end, cnt);
+                       ref_end, q_start, q_end, ckpt, cnt);
 }
 
 }  // namespace csv
