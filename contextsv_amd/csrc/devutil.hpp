@@ -19,6 +19,30 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
     return v;
 }
 
+// DPP forms (gfx9/CDNA): row_shr 1,2,4,8 inside each 16-lane row, then row_bcast:15 / row_bcast:31 carry the row
+// totals across rows. Six full-rate VALU ops and no LDS crossbar traffic, against six ds_bpermute round trips for the
+// shuffle form — the CIGAR kernels are VALU-issue-bound, so this matters.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v)
+{
+    v += dpp_u32<0x111, 0xf>(0u, v);   // row_shr:1
+    v += dpp_u32<0x112, 0xf>(0u, v);   // row_shr:2
+    v += dpp_u32<0x114, 0xf>(0u, v);   // row_shr:4
+    v += dpp_u32<0x118, 0xf>(0u, v);   // row_shr:8
+    v += dpp_u32<0x142, 0xa>(0u, v);   // row_bcast:15 -> rows 1 and 3
+    v += dpp_u32<0x143, 0xc>(0u, v);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+// total of the wave, as a scalar (lane 63 of the inclusive scan)
+__device__ __forceinline__ uint32_t wave_total_dpp(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum_dpp(v), 63);
+}
+
 __device__ __forceinline__ int32_t wave_incl_max(int32_t v)
 {
     const int l = lane_id();

@@ -1,5 +1,6 @@
 // hostabi.cpp — extern "C" hooks over the C++ host mirror so the parity tests and bench.py (ctypes)
 // can drive it. POD only; every function returns 0 or -1 (message via csvhost_last_error()).
+#include <chrono>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -8,7 +9,10 @@
 #include "khmm.h"
 #include "log.h"
 #include "sv_caller.h"
+#include "sort_select.h"
 #include "synth.h"
+#include <algorithm>
+#include <vector>
 
 namespace { std::string g_err; }
 #define GUARD(...) try { __VA_ARGS__; return 0; } catch (const std::exception &e) { g_err = e.what(); return -1; }
@@ -92,6 +96,20 @@ int csvhost_add_sv_calls(const csvhost_call *calls, uint64_t n, int64_t *ids_out
     })
 }
 
+// test hook for sort_select.h: ids that std::sort and std_sort_select leave at slot nth when sorting `keys`
+// descending by key only (ties make the difference between stable and unstable visible through the ids)
+int csvhost_sort_select_check(const uint32_t *keys, uint64_t n, uint64_t nth, int64_t *id_std, int64_t *id_sel)
+{
+    GUARD({
+        std::vector<uint32_t> a(n), b(n);
+        for (uint64_t i = 0; i < n; i++) a[i] = b[i] = (uint32_t)i;
+        auto cmp = [&](uint32_t x, uint32_t y) { return keys[x] > keys[y]; };
+        std::sort(a.begin(), a.end(), cmp);
+        *id_std = a[nth];
+        *id_sel = *csvhost::std_sort_select(b.begin(), b.end(), (std::ptrdiff_t)nth, cmp);
+    })
+}
+
 // ---- synthetic shards -------------------------------------------------------------------------
 struct csvhost_synth { SynthShard sh; };
 
@@ -141,6 +159,44 @@ int csvhost_process_resident_chromosome(csv_ctx *ctx, csv_shard *shard, const ui
             p.id = -1; p.aln_flags = (uint32_t)c.aln_type.to_ulong(); p.genotype = (int32_t)c.genotype; p.cn_state = c.cn_state; p.aln_offset = c.aln_offset;
             out[i] = p;
             if (alt_tag) alt_tag[i] = c.alt_allele == "<DEL>" ? 0 : (c.alt_allele == "<INS>" ? 1 : 2);
+        }
+    })
+}
+
+// n_steps passes over the same resident shard, software-pipelined (device chain of step i+1 overlaps the host merge of
+// step i). Returns the merged calls of the LAST step and its stats; ms_total = wall time of all steps.
+int csvhost_process_resident_pipelined(csv_ctx *ctx, csv_shard *shard, uint64_t n_steps, const uint64_t *seq_off, const uint8_t *seq,
+                                       double eps, double min_pts_pct, csvhost_call *out, uint8_t *alt_tag, uint64_t cap,
+                                       csvhost_chr_stats *st, double *ms_total, uint64_t *total_calls)
+{
+    GUARD({
+        SVCaller caller(ctx);
+        SeqStore ss; ss.seq_off = seq_off; ss.seq = seq;
+        std::vector<csv_shard *> shards(n_steps, shard);
+        std::vector<std::vector<SVCall>> calls;
+        std::vector<ChrStats> stats;
+        const auto t0 = std::chrono::steady_clock::now();
+        caller.processResidentChromosomesPipelined(shards, seq ? &ss : nullptr, eps, min_pts_pct, calls, stats);
+        *ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        uint64_t tot = 0;
+        for (auto &c : calls) tot += c.size();
+        *total_calls = tot;
+        if (n_steps) {
+            const ChrStats &cs = stats.back();
+            const std::vector<SVCall> &last = calls.back();
+            st->n_signatures = cs.n_signatures; st->n_del = cs.n_del; st->n_ins = cs.n_ins; st->depth_sum = cs.depth_sum;
+            st->depth_nonzero = cs.depth_nonzero; st->min_pts = cs.dbscan_min_pts; st->mean_cov = cs.mean_chr_cov;
+            double dev = 0, hm = 0;
+            for (auto &x : stats) { dev += x.ms_device; hm += x.ms_host_merge; }
+            st->ms_device = dev / n_steps; st->ms_host_merge = hm / n_steps; st->n_calls = last.size();
+            for (size_t i = 0; i < last.size() && i < cap; i++) {
+                const SVCall &c = last[i];
+                csvhost_call p;
+                p.start = c.start; p.end = c.end; p.sv_type = (int32_t)c.sv_type; p.cluster_size = c.cluster_size; p.hmm_likelihood = c.hmm_likelihood;
+                p.id = -1; p.aln_flags = (uint32_t)c.aln_type.to_ulong(); p.genotype = (int32_t)c.genotype; p.cn_state = c.cn_state; p.aln_offset = c.aln_offset;
+                out[i] = p;
+                if (alt_tag) alt_tag[i] = c.alt_allele == "<DEL>" ? 0 : (c.alt_allele == "<INS>" ? 1 : 2);
+            }
         }
     })
 }

@@ -2,9 +2,14 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 
 #include "log.h"
+#include "sort_select.h"
 
 namespace {
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -64,16 +69,17 @@ void SVCaller::mergeSignaturesWithLabels(const csv_sig *sig, const int32_t *labe
         const size_t sz = head[s + 1] - head[s];
         if (sz < 2) continue;
         uint32_t *m = member.data() + head[s];
-        std::sort(m, m + sz, [&](uint32_t a, uint32_t b) { return (sig[a].end - sig[a].start) > (sig[b].end - sig[b].start); });
+        // the slot std::sort(by length desc) would fill at [top/2] — selected in O(sz), see sort_select.h
         const size_t top = (size_t)std::max(1, (int)(sz * 0.2));
-        SVCall rep = toSVCall(sig[m[top / 2]], seq);
+        auto by_len_desc = [&](uint32_t a, uint32_t b) { return (sig[a].end - sig[a].start) > (sig[b].end - sig[b].start); };
+        const uint32_t pick = *csvhost::std_sort_select(m, m + sz, (std::ptrdiff_t)(top / 2), by_len_desc);
+        SVCall rep = toSVCall(sig[pick], seq);
         rep.cluster_size = (int)sz;
         merged.push_back(rep);
     }
 }
 
-void SVCaller::processResidentChromosome(const std::string &chr, csv_shard *shard, const SeqStore *seq, double eps, double pct,
-                                         std::vector<SVCall> &chr_sv_calls, ChrStats &st)
+void SVCaller::runDeviceChain(const std::string &chr, csv_shard *shard, double eps, double pct, DeviceOut &out, ChrStats &st)
 {
     const double t0 = now_ms();
     csv_chr_result res;
@@ -83,32 +89,85 @@ void SVCaller::processResidentChromosome(const std::string &chr, csv_shard *shar
     if (pct > 0.0)
         printMessage(chr + ": Mean chr. cov.: " + std::to_string(res.mean_cov) + " (DBSCAN min. pts.= " + std::to_string(res.min_pts) +
                      ", min. pts. pct.= " + std::to_string(pct) + ")");
-    std::vector<csv_sig> sig(res.n_sig);
-    std::vector<int32_t> lab(res.n_sig);
+    out.sig.resize(res.n_sig);
+    out.lab.resize(res.n_sig);
+    out.n_del = res.n_del; out.n_ins = res.n_ins;
     // sig_del/sig_ins and label_del/label_ins are adjacent in the shard's scratch: one copy each
-    check(ctx, csvgpu_download(ctx, sig.data(), res.sig_del, res.n_sig * sizeof(csv_sig)), "download signatures");
-    check(ctx, csvgpu_download(ctx, lab.data(), res.label_del, res.n_sig * sizeof(int32_t)), "download labels");
-    const double t1 = now_ms();
+    check(ctx, csvgpu_download(ctx, out.sig.data(), res.sig_del, res.n_sig * sizeof(csv_sig)), "download signatures");
+    check(ctx, csvgpu_download(ctx, out.lab.data(), res.label_del, res.n_sig * sizeof(int32_t)), "download labels");
+    st.ms_device = now_ms() - t0;
+}
 
-    // mergeSVs(chr_sv_calls, eps, min_pts, keep_noise=false) with the labels already computed on device.
-    // Every CIGAR call has hmm_likelihood == 0, so only the length-ranked branch of the representative choice
-    // can run (sv_object.cpp:187-244 of the reference); it is evaluated on the 16-byte signatures and an SVCall
-    // (with its strings) is materialised for the chosen member only.
+// mergeSVs(chr_sv_calls, eps, min_pts, keep_noise=false) with the labels already computed on device.
+// Every CIGAR call has hmm_likelihood == 0, so only the length-ranked branch of the representative choice
+// can run (sv_object.cpp:187-244 of the reference); it is evaluated on the 16-byte signatures and an SVCall
+// (with its strings) is materialised for the chosen member only.
+void SVCaller::hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st)
+{
+    const double t1 = now_ms();
+    const uint64_t n_sig = in.sig.size();
     chr_sv_calls.clear();
     printMessage(chr + ": Merging CIGAR...");
-    if (res.n_sig < 2) {                                   // mergeSVs returns early (:49-51)
-        for (uint64_t i = 0; i < res.n_sig; i++) chr_sv_calls.push_back(toSVCall(sig[i], seq));
+    if (n_sig < 2) {                                   // mergeSVs returns early (:49-51)
+        for (uint64_t i = 0; i < n_sig; i++) chr_sv_calls.push_back(toSVCall(in.sig[i], seq));
     } else {
-        const uint64_t type_n[2] = {res.n_del, res.n_ins};
+        const uint64_t type_n[2] = {in.n_del, in.n_ins};
         uint64_t base = 0;
         for (int t = 0; t < 2; t++) {
-            if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) chr_sv_calls.push_back(toSVCall(sig[base + i], seq));
-            else mergeSignaturesWithLabels(sig.data() + base, lab.data() + base, type_n[t], seq, chr_sv_calls);
+            if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) chr_sv_calls.push_back(toSVCall(in.sig[base + i], seq));
+            else mergeSignaturesWithLabels(in.sig.data() + base, in.lab.data() + base, type_n[t], seq, chr_sv_calls);
             base += type_n[t];
         }
     }
-    st.ms_device = t1 - t0; st.ms_host_merge = now_ms() - t1;
+    st.ms_host_merge = now_ms() - t1;
     printMessage(chr + ": Found " + std::to_string(getSVCount(chr_sv_calls)) + " SV candidates in the CIGAR string");
+}
+
+void SVCaller::processResidentChromosome(const std::string &chr, csv_shard *shard, const SeqStore *seq, double eps, double pct,
+                                         std::vector<SVCall> &chr_sv_calls, ChrStats &st)
+{
+    DeviceOut d;
+    runDeviceChain(chr, shard, eps, pct, d, st);
+    hostMerge(chr, d, seq, chr_sv_calls, st);
+}
+
+void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *> &shards, const SeqStore *seq, double eps, double pct,
+                                                   std::vector<std::vector<SVCall>> &calls, std::vector<ChrStats> &stats)
+{
+    const size_t n = shards.size();
+    calls.assign(n, {});
+    stats.assign(n, ChrStats());
+    std::vector<DeviceOut> slot(2);                       // double buffer between the device thread and the merge thread
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t produced = 0, consumed = 0;                    // shards handed over / merged
+    std::exception_ptr worker_err;
+    std::thread worker([&] {
+        try {
+            for (size_t i = 0; i < n; i++) {
+                { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return produced > i || produced == SIZE_MAX; }); if (produced == SIZE_MAX) return; }
+                hostMerge("shard" + std::to_string(i), slot[i & 1], seq, calls[i], stats[i]);
+                { std::lock_guard<std::mutex> l(mu); consumed = i + 1; }
+                cv.notify_all();
+            }
+        } catch (...) { worker_err = std::current_exception(); std::lock_guard<std::mutex> l(mu); consumed = SIZE_MAX; cv.notify_all(); }
+    });
+    try {
+        for (size_t i = 0; i < n; i++) {
+            // slot i&1 is free once shard i-2 has been merged
+            { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return consumed == SIZE_MAX || consumed + 2 > i; }); if (consumed == SIZE_MAX) break; }
+            runDeviceChain("shard" + std::to_string(i), shards[i], eps, pct, slot[i & 1], stats[i]);
+            { std::lock_guard<std::mutex> l(mu); produced = i + 1; }
+            cv.notify_all();
+        }
+    } catch (...) {
+        { std::lock_guard<std::mutex> l(mu); produced = SIZE_MAX; }
+        cv.notify_all();
+        worker.join();
+        throw;
+    }
+    worker.join();
+    if (worker_err) std::rethrow_exception(worker_err);
 }
 
 void SVCaller::processChromosome(const std::string &chr, const csv_reads &reads, const SeqStore *seq, uint32_t depth_len, double eps,

@@ -44,10 +44,25 @@ public:
     void processResidentChromosome(const std::string &chr, csv_shard *shard, const SeqStore *seq, double dbscan_epsilon,
                                    double dbscan_min_pts_pct, std::vector<SVCall> &chr_sv_calls, ChrStats &stats);
 
+    // Many resident shards back to back, software-pipelined the way a whole-genome run is: while the device runs shard
+    // i+1 (scan -> depth -> ordering -> DBSCAN), a host worker thread does shard i's representative choice. The reference
+    // gets this overlap from its chromosome thread pool (sv_caller.cpp:827-863); here one GPU stream + one merge thread.
+    // calls[i] / stats[i] correspond to shards[i] (the same shard may appear several times).
+    void processResidentChromosomesPipelined(const std::vector<csv_shard *> &shards, const SeqStore *seq, double dbscan_epsilon,
+                                             double dbscan_min_pts_pct, std::vector<std::vector<SVCall>> &calls,
+                                             std::vector<ChrStats> &stats);
+
     // signature -> SVCall with the reference's field values (sv_caller.cpp:569-643)
     static SVCall toSVCall(const csv_sig &s, const SeqStore *seq);
     static void mergeSignaturesWithLabels(const csv_sig *sig, const int32_t *labels, uint64_t n, const SeqStore *seq, std::vector<SVCall> &merged);
 
 private:
     csv_ctx *ctx;
+    struct DeviceOut {                       // what the device chain of one shard hands to the host merge
+        std::vector<csv_sig> sig;
+        std::vector<int32_t> lab;
+        uint64_t n_del = 0, n_ins = 0;
+    };
+    void runDeviceChain(const std::string &chr, csv_shard *shard, double eps, double pct, DeviceOut &out, ChrStats &st);
+    static void hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st);
 };

@@ -137,6 +137,22 @@ __device__ __forceinline__ ReadMd depth_load_md(uint64_t kk, uint64_t k_hi, cons
     return m;
 }
 
+__device__ __forceinline__ uint32_t depth_grab(unsigned int *counter, int lane)
+{
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(counter, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+__device__ __forceinline__ void depth_load4(const uint32_t *__restrict__ cigar, uint64_t n_cigar, int vec_ok, uint64_t idx, uint32_t (&w)[4])
+{
+    if (vec_ok && idx + 4 <= n_cigar) { const uint4 v = *reinterpret_cast<const uint4 *>(cigar + idx); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = (idx + k < n_cigar) ? cigar[idx + k] : (uint32_t)OP_P;
+    }
+}
+
 __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int vec_ok, int dvec_ok,
@@ -151,6 +167,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     __shared__ uint64_t range_s[2];
     __shared__ unsigned long long blk_sum;
     __shared__ unsigned int blk_nz;
+    __shared__ unsigned int next_read;
 
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -159,6 +176,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
 
     for (int i = threadIdx.x; i < DEPTH_TILE + 4; i += DEPTH_THREADS) diff[i] = 0;
     if (threadIdx.x == 0) {
+        next_read = 0;
         // reads cover 1-based positions [pos+1, ref_end]; candidates: pmax_end >= T0 and pos+1 < T1
         uint64_t lo = 0, hi = n_reads;
         while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if ((int64_t)pmax_end[mid] >= (int64_t)T0) hi = mid; else lo = mid + 1; }
@@ -171,10 +189,14 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     __syncthreads();
     const uint64_t k_lo = range_s[0], k_hi = range_s[1];
 
-    ReadMd md = depth_load_md(k_lo + wave, k_hi, ord, pos, flag, cigar_off, ref_end, T0);
-    for (uint64_t kk = k_lo + wave; kk < k_hi; kk += DEPTH_WAVES) {
+    // reads are handed to the waves through an LDS counter (their cost varies a lot: most candidates end left of the
+    // tile and are skipped, long ones take many chunks), with the next read's metadata already in flight
+    uint64_t kk = k_lo + depth_grab(&next_read, lane);
+    ReadMd md = depth_load_md(kk, k_hi, ord, pos, flag, cigar_off, ref_end, T0);
+    while (kk < k_hi) {
         const ReadMd cur = md;
-        md = depth_load_md(kk + DEPTH_WAVES, k_hi, ord, pos, flag, cigar_off, ref_end, T0);   // next read's metadata in flight
+        kk = k_lo + depth_grab(&next_read, lane);
+        md = depth_load_md(kk, k_hi, ord, pos, flag, cigar_off, ref_end, T0);
         if (!cur.ok || cur.c1 <= cur.c0) continue;
         const uint64_t c0 = cur.c0, c1 = cur.c1;
         const uint64_t p1 = cur.p1;
@@ -193,27 +215,14 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                 if (n_left < WAVE) break;
             }
         }
-        uint32_t w[4], wn[4];
-        {
-            const uint64_t idx = chunk + (uint64_t)lane * 4;
-            if (vec_ok && idx + 4 <= n_cigar) { const uint4 v = *reinterpret_cast<const uint4 *>(cigar + idx); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) w[k] = (idx + k < n_cigar) ? cigar[idx + k] : (uint32_t)OP_P;
-            }
-        }
+        uint32_t w[4], w1[4], w2[4];
+        depth_load4(cigar, n_cigar, vec_ok, chunk + (uint64_t)lane * 4, w);
+        if (chunk + 4 * WAVE < c1) depth_load4(cigar, n_cigar, vec_ok, chunk + 4 * WAVE + (uint64_t)lane * 4, w1);
         for (; chunk < c1; chunk += 4 * WAVE) {
             if (p1 + ref_carry >= T1) break;                                   // rest of the read lies right of the tile
             const uint64_t idx = chunk + (uint64_t)lane * 4;
             const bool more = chunk + 4 * WAVE < c1;
-            if (more) {                                                        // prefetch the next 1 KiB
-                const uint64_t idn = idx + 4 * WAVE;
-                if (vec_ok && idn + 4 <= n_cigar) { const uint4 v = *reinterpret_cast<const uint4 *>(cigar + idn); wn[0] = v.x; wn[1] = v.y; wn[2] = v.z; wn[3] = v.w; }
-                else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) wn[k] = (idn + k < n_cigar) ? cigar[idn + k] : (uint32_t)OP_P;
-                }
-            }
+            if (chunk + 8 * WAVE < c1) depth_load4(cigar, n_cigar, vec_ok, idx + 8 * WAVE, w2);   // two chunks in flight ahead
             uint32_t len[4], rl[4], aln = 0, lane_ref = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
             ref_carry += __shfl(incl, 63, 64);
             if (more) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) w[k] = wn[k];
+                for (int k = 0; k < 4; k++) { w[k] = w1[k]; w1[k] = w2[k]; }
             }
         }
     }

@@ -40,6 +40,45 @@ __device__ __forceinline__ Chunk load_chunk(const uint32_t *__restrict__ cigar, 
     return c;
 }
 
+// first read index r in [0, n] with cigar_off[r] >= target (cigar_off is non-decreasing); 64-ary search by one wave
+__device__ __forceinline__ uint64_t wave_lower_bound(const uint64_t *__restrict__ cigar_off, uint64_t n, uint64_t target, int lane)
+{
+    uint64_t lo = 0, hi = n;                 // answer in [lo, hi]
+    while (hi - lo > 0) {
+        const uint64_t span = hi - lo;
+        const uint64_t step = (span + 63) / 64;
+        const uint64_t probe = lo + (uint64_t)lane * step;          // probes lo, lo+step, ...
+        const bool ge = probe >= hi || cigar_off[probe] >= target;  // monotone in lane
+        const uint64_t m = __ballot(ge);
+        const int first_ge = m ? __ffsll((long long)m) - 1 : 64;
+        // answer lies in (probe[first_ge-1], probe[first_ge]]
+        const uint64_t new_hi = first_ge < 64 ? min(lo + (uint64_t)first_ge * step, hi) : hi;
+        const uint64_t new_lo = first_ge > 0 ? lo + (uint64_t)(first_ge - 1) * step + 1 : lo;
+        if (first_ge == 0) return lo;
+        lo = new_lo; hi = new_hi;
+        if (step == 1) return hi;
+    }
+    return lo;
+}
+
+struct ScanMd {
+    uint64_t c0, c1;
+    uint32_t p0, fl, mq, unsorted;
+};
+__device__ __forceinline__ ScanMd scan_load_md(uint64_t r, uint64_t n_reads, const int32_t *__restrict__ pos,
+                                               const uint16_t *__restrict__ flag, const uint8_t *__restrict__ mapq,
+                                               const uint64_t *__restrict__ cigar_off)
+{
+    ScanMd m; m.c0 = 0; m.c1 = 0; m.p0 = 0; m.fl = 0; m.mq = 0; m.unsorted = 0;
+    if (r < n_reads) {
+        m.c0 = cigar_off[r]; m.c1 = cigar_off[r + 1];
+        const int32_t p = pos[r];
+        m.p0 = (uint32_t)p; m.fl = flag[r]; m.mq = mapq[r];
+        m.unsorted = (r > 0 && p < pos[r - 1]) ? 1u : 0u;
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint8_t *__restrict__ mapq, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
@@ -58,148 +97,177 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
 
     uint32_t my_max_start = 0, my_max_len = 0, my_n_del = 0;
 
+    // Work split: read lengths are log-normal, so handing out reads round-robin leaves the slowest wave with ~1.5x the
+    // mean work (measured: waves alive 65 % of the kernel). Instead every wave takes the CONTIGUOUS run of reads whose
+    // first CIGAR word falls into its equal share of the word array — cigar_off is the cumulative word count, so the
+    // split points are found with a 64-ary search done by the wave itself. Balanced to within one read, and the wave's
+    // reads are contiguous in memory.
+    const uint64_t n_waves = (uint64_t)gridDim.x * SCAN_WAVES;
     const uint64_t wave_gid = (uint64_t)blockIdx.x * SCAN_WAVES + wave;
-    const uint64_t wave_stride = (uint64_t)gridDim.x * SCAN_WAVES;
+    const uint64_t share = (n_cigar + n_waves - 1) / n_waves;
+    const uint64_t r_begin = wave_lower_bound(cigar_off, n_reads, wave_gid * share, lane);
+    const uint64_t r_end = (wave_gid + 1 == n_waves) ? n_reads : wave_lower_bound(cigar_off, n_reads, (wave_gid + 1) * share, lane);
 
-    for (uint64_t r = wave_gid; r < n_reads; r += wave_stride) {
-        const uint64_t c0 = cigar_off[r], c1 = cigar_off[r + 1];
-        const uint32_t p0 = (uint32_t)pos[r];
-        const uint32_t fl = flag[r];
-        const uint32_t mq = mapq[r];
+    // Software pipeline across reads: while read r is walked, the metadata of the wave's next read is already in
+    // flight, and its first chunk is requested when the current read reaches its last chunk.
+    ScanMd md = scan_load_md(r_begin < r_end ? r_begin : n_reads, n_reads, pos, flag, mapq, cigar_off);
+    Chunk first = load_chunk(cigar, (md.c0 & ~255ull) + (uint64_t)lane * 4, n_cigar, vec_ok);
+    for (uint64_t r = r_begin; r < r_end; r++) {
+        const ScanMd cm = md;
+        const uint64_t c0 = cm.c0, c1 = cm.c1;
+        const uint32_t p0 = cm.p0;
+        const uint32_t fl = cm.fl;
+        const bool have_next = r + 1 < r_end;
+        if (have_next) md = scan_load_md(r + 1, n_reads, pos, flag, mapq, cigar_off);
+        bool next_first_issued = false;
         // sv_caller.cpp:526
-        const bool emit_ok = emit && !(fl & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && mq >= min_mapq;
-        if (lane == 0 && r > 0 && pos[r] < pos[r - 1]) cnt->unsorted = 1u;
+        const bool emit_ok = emit && !(fl & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && cm.mq >= min_mapq;
+        if (lane == 0 && cm.unsorted) cnt->unsorted = 1u;
 
-        uint32_t ref_carry = 0;      // reference bases consumed so far (pos - aln_start)
-        uint32_t q_carry = 0;        // query bases consumed so far (plain; getAlignmentReadPositions)
-        uint32_t skip_carry = 0;     // lengths of soft clips skipped by the `continue` at sv_caller.cpp:602-604
+        // The kernel is VALU-issue-bound, so the common chunk does the minimum: decode, ONE DPP scan (reference
+        // cursor: needed for the checkpoint and ref_end), lane-local query sums. Query cursors, skipped-clip
+        // bookkeeping and signature assembly run only in chunks that contain an op >= min_oplen or that still
+        // have to find query_start.
+        uint32_t ref_carry = 0;      // reference bases consumed before this chunk (wave-uniform)
+        uint32_t acc_q = 0;          // this lane's share of the query bases consumed before this chunk
+        uint32_t acc_skip = 0;       // this lane's share of soft clips skipped by the `continue` at sv_caller.cpp:602-604
         int32_t  qs = -1;            // query_start
 
-        // chunks are aligned to 256 words (1 KiB) globally, so that a chunk boundary is a checkpoint slot
-        const uint64_t base = c0 & ~255ull;
-        Chunk cur = load_chunk(cigar, base + (uint64_t)lane * 4, n_cigar, vec_ok);
-        for (uint64_t chunk = base; chunk < c1; chunk += 4 * WAVE) {
-            const uint64_t idx = chunk + (uint64_t)lane * 4;
+        const uint32_t n_words = (uint32_t)(c1 - c0);
+        const uint64_t base = c0 & ~255ull;       // chunks are aligned to 256 words (1 KiB): a chunk boundary is a checkpoint slot
+        int32_t rel = (int32_t)(base - c0) + lane * 4;   // index of this lane's first word relative to the read's first word
+        Chunk cur = first;
+        for (uint64_t chunk = base; chunk < c1; chunk += 4 * WAVE, rel += 4 * WAVE) {
             if (lane == 0 && chunk > c0) ckpt[chunk >> 8] = ref_carry;     // reference offset of this read at word `chunk` (depth.hip)
             Chunk nxt;
             const bool more = chunk + 4 * WAVE < c1;
-            if (more) nxt = load_chunk(cigar, idx + 4 * WAVE, n_cigar, vec_ok);   // prefetch next 1 KiB
+            if (more) nxt = load_chunk(cigar, chunk + 4 * WAVE + (uint64_t)lane * 4, n_cigar, vec_ok);   // prefetch next 1 KiB
+            else if (have_next) {                                                                        // last chunk: next read's first
+                first = load_chunk(cigar, (md.c0 & ~255ull) + (uint64_t)lane * 4, n_cigar, vec_ok);
+                next_first_issued = true;
+            }
 
             uint32_t len[4], op[4], rl[4], ql[4];
-            uint32_t lane_ref = 0, lane_q = 0;
+            uint32_t lane_ref = 0, lane_q = 0, big = 0, qst = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const bool valid = (idx + k >= c0) && (idx + k < c1);
+                const bool valid = (uint32_t)(rel + k) < n_words;          // also false for rel + k < 0
                 len[k] = valid ? (cur.w[k] >> 4) : 0u;
                 op[k] = valid ? (cur.w[k] & 15u) : (uint32_t)OP_P;
                 rl[k] = ((REF_OPS >> op[k]) & 1u) ? len[k] : 0u;
                 ql[k] = ((QRY_OPS >> op[k]) & 1u) ? len[k] : 0u;
                 lane_ref += rl[k];
                 lane_q += ql[k];
+                big |= (len[k] >= min_oplen) ? 1u : 0u;
+                qst |= (QST_OPS >> op[k]) & 1u;
             }
-            const uint32_t incl_ref = wave_incl_sum(lane_ref);
-            const uint32_t incl_q = wave_incl_sum(lane_q);
-            uint32_t rp = p0 + ref_carry + (incl_ref - lane_ref);   // reference `pos` before this lane's first op
-            uint32_t qp = q_carry + (incl_q - lane_q);              // plain query cursor before this lane's first op
+            const uint32_t incl_ref = wave_incl_sum_dpp(lane_ref);
+            const bool need_q = (qs < 0) || (emit_ok && __ballot(big != 0) != 0);
+            if (need_q) {
+                // ---------------- slow path: query cursors --------------------------------------------------
+                const uint32_t q_carry = wave_total_dpp(acc_q);
+                const uint32_t incl_q = wave_incl_sum_dpp(lane_q);
+                const uint32_t rp = p0 + ref_carry + (incl_ref - lane_ref);   // reference `pos` before this lane's first op
+                const uint32_t qp = q_carry + (incl_q - lane_q);              // plain query cursor before this lane's first op
 
-            // query_start = cursor at the first M/I/=/X op (sv_caller.cpp:674-676)
-            if (qs < 0) {
-                bool found = false;
-                uint32_t q_at = 0, acc = qp;
+                // query_start = cursor at the first M/I/=/X op (sv_caller.cpp:674-676)
+                if (qs < 0) {
+                    const uint64_t m = __ballot(qst != 0);
+                    if (m) {
+                        bool found = false;
+                        uint32_t q_at = 0, acc = qp;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (!found && ((QST_OPS >> op[k]) & 1u)) { found = true; q_at = acc; }
-                    acc += ql[k];
-                }
-                const uint64_t m = __ballot(found);
-                if (m) {
-                    const int src = __ffsll((long long)m) - 1;
-                    qs = (int32_t)__shfl(q_at, src, 64);
-                }
-            }
-
-            if (emit_ok) {
-                // candidate ops: len >= min_oplen and I / S / D (sv_caller.cpp:566-643)
-                uint32_t cand = 0, skipped = 0, lane_skip = 0;
-                {
-                    uint32_t rpk = rp;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (len[k] >= min_oplen) {
-                            if (op[k] == OP_I || op[k] == OP_D) cand |= 1u << k;
-                            else if (op[k] == OP_S) {
-                                if ((uint32_t)(rpk + 1u) >= depth_len) { skipped |= 1u << k; lane_skip += len[k]; }
-                                else cand |= 1u << k;
-                            }
+                        for (int k = 0; k < 4; k++) {
+                            if (!found && ((QST_OPS >> op[k]) & 1u)) { found = true; q_at = acc; }
+                            acc += ql[k];
                         }
-                        rpk += rl[k];
+                        qs = (int32_t)__shfl(q_at, __ffsll((long long)m) - 1, 64);
                     }
                 }
-                uint32_t skip_before = skip_carry;
-                if (__ballot(skipped != 0)) {                 // rare: clip past the contig end
-                    const uint32_t incl_s = wave_incl_sum(lane_skip);
-                    skip_before += incl_s - lane_skip;
-                    skip_carry += __shfl(incl_s, 63, 64);
-                }
-                if (__ballot(cand != 0)) {
-                    uint32_t rpk = rp, qpk = qp, skk = skip_before;
+
+                if (emit_ok && __ballot(big != 0) != 0) {
+                    // candidate ops: len >= min_oplen and I / S / D (sv_caller.cpp:566-643)
+                    uint32_t cand = 0, skipped = 0, lane_skip = 0;
+                    {
+                        uint32_t rpk = rp;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool e = (cand >> k) & 1u;
-                        const uint64_t m = __ballot(e);
-                        if (m) {
-                            const uint32_t n_e = (uint32_t)__popcll(m);
-                            const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
-                            csv_sig s;
-                            s.start = rpk + 1u;
-                            s.end = s.start + len[k] - 1u;
-                            s.read = (uint32_t)r;
-                            const uint32_t kind = (op[k] == OP_I) ? CSV_KIND_INS : (op[k] == OP_D ? CSV_KIND_DEL : CSV_KIND_CLIP);
-                            s.qpos_kind = ((qpk - skk) << 2) | kind;
-                            // reserve n_e slots of the workgroup buffer (LDS CAS), else go straight to HBM
-                            uint32_t slot = 0xffffffffu;
-                            if (lane == 0) {
-                                uint32_t old = buf_n;
-                                while (old + n_e <= SIG_BUF) {
-                                    const uint32_t seen = atomicCAS(&buf_n, old, old + n_e);
-                                    if (seen == old) { slot = old; break; }
-                                    old = seen;
+                        for (int k = 0; k < 4; k++) {
+                            if (len[k] >= min_oplen) {
+                                if (op[k] == OP_I || op[k] == OP_D) cand |= 1u << k;
+                                else if (op[k] == OP_S) {
+                                    if ((uint32_t)(rpk + 1u) >= depth_len) { skipped |= 1u << k; lane_skip += len[k]; }
+                                    else cand |= 1u << k;
                                 }
                             }
-                            slot = __shfl(slot, 0, 64);
-                            if (slot != 0xffffffffu) {
-                                if (e) buf[slot + rank] = s;
-                            } else {
-                                unsigned long long g = 0;
-                                if (lane == 0) g = atomicAdd(&cnt->n_sig, (unsigned long long)n_e);
-                                g = __shfl(g, 0, 64);
-                                if (e && g + rank < sig_cap) sig_out[g + rank] = s;
-                            }
-                            if (e) {
-                                my_max_start = max(my_max_start, s.start);
-                                my_max_len = max(my_max_len, s.end - s.start);
-                                my_n_del += (kind == CSV_KIND_DEL);
-                            }
+                            rpk += rl[k];
                         }
-                        if ((skipped >> k) & 1u) skk += len[k];
-                        rpk += rl[k];
-                        qpk += ql[k];
+                    }
+                    uint32_t skip_before = wave_total_dpp(acc_skip);
+                    if (__ballot(skipped != 0)) {                 // rare: clip past the contig end
+                        skip_before += wave_incl_sum_dpp(lane_skip) - lane_skip;
+                        acc_skip += lane_skip;
+                    }
+                    if (__ballot(cand != 0)) {
+                        uint32_t rpk = rp, qpk = qp, skk = skip_before;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const bool e = (cand >> k) & 1u;
+                            const uint64_t m = __ballot(e);
+                            if (m) {
+                                const uint32_t n_e = (uint32_t)__popcll(m);
+                                const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+                                csv_sig sg;
+                                sg.start = rpk + 1u;
+                                sg.end = sg.start + len[k] - 1u;
+                                sg.read = (uint32_t)r;
+                                const uint32_t kind = (op[k] == OP_I) ? CSV_KIND_INS : (op[k] == OP_D ? CSV_KIND_DEL : CSV_KIND_CLIP);
+                                sg.qpos_kind = ((qpk - skk) << 2) | kind;
+                                // reserve n_e slots of the workgroup buffer (LDS CAS), else go straight to HBM
+                                uint32_t slot = 0xffffffffu;
+                                if (lane == 0) {
+                                    uint32_t old = buf_n;
+                                    while (old + n_e <= SIG_BUF) {
+                                        const uint32_t seen = atomicCAS(&buf_n, old, old + n_e);
+                                        if (seen == old) { slot = old; break; }
+                                        old = seen;
+                                    }
+                                }
+                                slot = __shfl(slot, 0, 64);
+                                if (slot != 0xffffffffu) {
+                                    if (e) buf[slot + rank] = sg;
+                                } else {
+                                    unsigned long long g = 0;
+                                    if (lane == 0) g = atomicAdd(&cnt->n_sig, (unsigned long long)n_e);
+                                    g = __shfl(g, 0, 64);
+                                    if (e && g + rank < sig_cap) sig_out[g + rank] = sg;
+                                }
+                                if (e) {
+                                    my_max_start = max(my_max_start, sg.start);
+                                    my_max_len = max(my_max_len, sg.end - sg.start);
+                                    my_n_del += (kind == CSV_KIND_DEL);
+                                }
+                            }
+                            if ((skipped >> k) & 1u) skk += len[k];
+                            rpk += rl[k];
+                            qpk += ql[k];
+                        }
                     }
                 }
             }
-
-            ref_carry += __shfl(incl_ref, 63, 64);
-            q_carry += __shfl(incl_q, 63, 64);
+            acc_q += lane_q;
+            ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)incl_ref, 63);
             if (more) cur = nxt;
         }
+        if (have_next && !next_first_issued) first = load_chunk(cigar, (md.c0 & ~255ull) + (uint64_t)lane * 4, n_cigar, vec_ok);
 
+        const uint32_t q_total = wave_total_dpp(acc_q);
         if (lane == 0) {
             // htslib bam_endpos: pos + rlen, rlen == 0 (or unmapped) -> 1
             uint32_t rlen = (fl & F_UNMAP) ? 0u : ref_carry;
             if (rlen == 0) rlen = 1;
             ref_end[r] = (int32_t)(p0 + rlen);
             q_start[r] = qs < 0 ? 0 : qs;
-            q_end[r] = (int32_t)q_carry;
+            q_end[r] = (int32_t)q_total;
         }
     }
 
@@ -232,8 +300,16 @@ void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t dep
                        int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt)
 {
     if (d.n_reads == 0) return;
+    // persistent-style grid: exactly as many workgroups as are resident at once (waves stride over the reads),
+    // so there is no partially filled second round of workgroups
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_kernel, SCAN_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
+        blocks_per_cu = occ;
+    }
     uint64_t want = (d.n_reads + SCAN_WAVES - 1) / SCAN_WAVES;
-    uint64_t cap = (uint64_t)n_cu * 8;                    // 8 workgroups of 4 waves per CU = full occupancy
+    uint64_t cap = (uint64_t)n_cu * blocks_per_cu;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     hipLaunchKernelGGL(cigar_scan_kernel, dim3(grid), dim3(SCAN_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,

@@ -46,7 +46,10 @@ def load() -> C.CDLL:
     lib.csvhost_synth_view.argtypes = [_P, C.POINTER(_lib.csv_reads), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P)]
     lib.csvhost_synth_free.argtypes = [_P]
     lib.csvhost_process_resident_chromosome.argtypes = [_P, _P, _P, _P, C.c_double, C.c_double, _P, _P, C.c_uint64, C.POINTER(chr_stats)]
+    lib.csvhost_process_resident_pipelined.argtypes = [_P, _P, C.c_uint64, _P, _P, C.c_double, C.c_double, _P, _P, C.c_uint64,
+                                                       C.POINTER(chr_stats), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.csvhost_read_chmm.argtypes = [C.c_char_p, C.POINTER(_lib.csv_hmm), C.POINTER(C.c_int32)]
+    lib.csvhost_sort_select_check.argtypes = [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -151,6 +154,28 @@ def process_resident_chromosome(ctx: Context, shard: Shard, eps: float, min_pts_
                                                       capacity, C.byref(st)))
     n = min(st.n_calls, capacity)
     return out[:n].copy(), tag[:n].copy(), st
+
+
+def process_resident_pipelined(ctx: Context, shard: Shard, n_steps: int, eps: float, min_pts_pct: float, seq_off_ptr=None, seq_ptr=None,
+                               capacity: int = 1 << 20):
+    """n_steps pipelined passes over one resident shard (device chain of step i+1 overlaps the host merge of step i).
+    -> (merged calls of the last step, alt tags, stats averaged over steps, wall ms, total merged calls)."""
+    out = np.zeros(capacity, CALL_DTYPE)
+    tag = np.zeros(capacity, np.uint8)
+    st = chr_stats()
+    ms, tot = C.c_double(0), C.c_uint64(0)
+    _check(load().csvhost_process_resident_pipelined(ctx.h, shard.h, n_steps, seq_off_ptr, seq_ptr, eps, min_pts_pct, out.ctypes.data,
+                                                     tag.ctypes.data, capacity, C.byref(st), C.byref(ms), C.byref(tot)))
+    n = min(st.n_calls, capacity)
+    return out[:n].copy(), tag[:n].copy(), st, ms.value, tot.value
+
+
+def sort_select_check(keys: np.ndarray, nth: int):
+    """(id std::sort leaves at slot nth, id std_sort_select returns) for a descending sort by key."""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    a, b = C.c_int64(-1), C.c_int64(-1)
+    _check(load().csvhost_sort_select_check(keys.ctypes.data, len(keys), nth, C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def read_chmm(path: str):
