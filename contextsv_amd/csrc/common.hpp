@@ -145,8 +145,10 @@ size_t exclusive_sum_tmp_bytes(uint64_t n);
 size_t dbscan_tmp_bytes(uint64_t n);
 // s,e sorted by start; oid = original index of each sorted position (nullptr: identity).
 // min_pts read from *d_min_pts when d_min_pts != nullptr, else the immediate.
+// split: positions [0,split) and [split,n) are two independent sets clustered side by side (split == n: one set;
+// only honoured when oid == nullptr).
 void launch_dbscan_iv_sorted(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint32_t *oid,
-                             uint64_t n, double eps, int min_pts, const int *d_min_pts, int32_t *labels, void *tmp);
+                             uint64_t n, uint64_t split, double eps, int min_pts, const int *d_min_pts, int32_t *labels, void *tmp);
 // dbscan1d.hip
 void launch_dbscan_1d_batched(hipStream_t s, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg,
                               double eps, int min_pts, int32_t *labels, unsigned int *too_large_flag);

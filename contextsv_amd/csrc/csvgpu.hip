@@ -171,11 +171,11 @@ static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, u
 {
     if (!n) return;
     TimerScope ts(ctx, CSV_K_SORT);
-    const int len_bits = std::max(1, bits_of(max_len));
+    (void)max_len;
     const int start_bits = std::max(1, bits_of(max_start));
-    const int type_pos = with_type ? len_bits + start_bits : -1;
-    const int key_bits = len_bits + start_bits + (with_type ? 1 : 0);
-    launch_sig_make_keys(ctx->stream, sig_raw, n, len_bits, type_pos, w.k0, w.v0);
+    const int type_pos = with_type ? start_bits : -1;
+    const int key_bits = start_bits + (with_type ? 1 : 0);
+    launch_sig_make_keys(ctx->stream, sig_raw, n, 0, type_pos, w.k0, w.v0);
     const int in_out = launch_radix_sort_u64(ctx->stream, w.k0, w.v0, w.k1, w.v1, n, key_bits, w.tmp);
     launch_sig_fix_ties_gather(ctx->stream, sig_raw, in_out ? w.k1 : w.k0, in_out ? w.v1 : w.v0, n, sig_sorted, start_out, end_out);
 }
@@ -234,7 +234,7 @@ static int dbscan_iv_chain(csv_ctx *ctx, Arena &a, const uint32_t *d_start, cons
     const bool unsorted = *(unsigned int *)ctx->pinned != 0;
     if (!unsorted) {
         TimerScope ts(ctx, CSV_K_DBSCAN);
-        launch_dbscan_iv_sorted(ctx->stream, d_start, d_end, nullptr, n, eps, min_pts, nullptr, d_labels, tmp);
+        launch_dbscan_iv_sorted(ctx->stream, d_start, d_end, nullptr, n, n, eps, min_pts, nullptr, d_labels, tmp);
         return CSV_OK;
     }
     SortWs w;
@@ -250,7 +250,7 @@ static int dbscan_iv_chain(csv_ctx *ctx, Arena &a, const uint32_t *d_start, cons
         launch_gather_u32(ctx->stream, d_end, perm, n, e_s);
     }
     TimerScope ts(ctx, CSV_K_DBSCAN);
-    launch_dbscan_iv_sorted(ctx->stream, s_s, e_s, perm, n, eps, min_pts, nullptr, d_labels, tmp);
+    launch_dbscan_iv_sorted(ctx->stream, s_s, e_s, perm, n, n, eps, min_pts, nullptr, d_labels, tmp);
     return CSV_OK;
 }
 static size_t dbscan_iv_chain_bytes(uint64_t n) { return 512 + dbscan_tmp_bytes(n) + sortws_bytes(n) + 2 * align_up(n * 4, 256) + 1024; }
@@ -744,7 +744,7 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
     const uint64_t n = h.n_sig, n_del = h.n_del, n_ins = n - n_del;
 
     // shard scratch: sorted signatures, SoA start/end, labels, sort + dbscan workspace (grow-only)
-    const uint64_t n_big = std::max(n_del, n_ins);
+    const uint64_t n_big = n;
     const size_t need = align_up(n * sizeof(csv_sig), 256) + 3 * align_up(n * 4 + 16, 256) + sortws_bytes(n) + dbscan_tmp_bytes(n_big) + 4096;
     if (need > sh->scratch_cap) {
         if (sh->scratch) CSV_HIP(ctx, hipFree(sh->scratch));
@@ -772,8 +772,8 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
     // per-type interval DBSCAN (mergeSVs walks DEL ... INS, sv_object.cpp:62-68)
     {
         TimerScope ts(ctx, CSV_K_DBSCAN);
-        if (n_del) launch_dbscan_iv_sorted(s, st, en, nullptr, n_del, eps, 0, &cnt->min_pts, labels, db_tmp);
-        if (n_ins) launch_dbscan_iv_sorted(s, st + n_del, en + n_del, nullptr, n_ins, eps, 0, &cnt->min_pts, labels + n_del, db_tmp);
+        // DEL calls [0, n_del) and INS calls [n_del, n) are clustered side by side in the same five launches
+        if (n) launch_dbscan_iv_sorted(s, st, en, nullptr, n, n_del, eps, 0, &cnt->min_pts, labels, db_tmp);
     }
     if ((rc = read_counters(ctx, cnt, h))) return rc;                     // final sync: scalars for the caller
     res->n_sig = n; res->n_del = n_del; res->n_ins = n_ins;

@@ -17,7 +17,7 @@
 // padded by 2 bp because acceptance is decided by the ROUNDED double expression; inside the window
 // the reference's exact expression is evaluated (devutil.hpp iv_neighbor). So O(n*w) instead of O(n^2).
 //
-// Four kernels: neighbour count -> lock-free union-find over core pairs (agent-scope atomics; larger
+// Five launches (for one set or for two sets side by side): neighbour count (+ union-find init) -> lock-free union-find over core pairs (agent-scope atomics; larger
 // root linked under smaller, so a component's root is its minimum original index) -> roots flagged
 // and ranked by an exclusive scan in original-index space -> labels.
 // The same machinery, instantiated with the 1-D metric |a-b| <= eps, serves DBSCAN1D segments that
@@ -62,17 +62,26 @@ struct PointMetric {                   // p = points sorted ascending (int order
     }
 };
 
+// Two independent point sets can share every launch: positions [0, split) are one set, [split, n) the other (the DEL
+// and INS calls of a chromosome). A window never leaves its own set; cluster ids restart at 0 in the second set.
 template <class M>
-__global__ void db_count_kernel(M m, uint64_t n, int min_pts_imm, const int *__restrict__ d_min_pts, uint8_t *__restrict__ core)
+__global__ void db_count_kernel(M m, uint64_t n, uint64_t split, int min_pts_imm, const int *__restrict__ d_min_pts,
+                                const uint32_t *__restrict__ oid, uint8_t *__restrict__ core, uint32_t *__restrict__ parent,
+                                uint32_t *__restrict__ is_root)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == n) is_root[n] = 0;
     if (i >= n) return;
+    const uint32_t me = oid ? oid[i] : (uint32_t)i;
+    parent[me] = me;                                   // union-find + root flags start here (no separate init launch)
+    is_root[me] = 0;
     const int min_pts = d_min_pts ? *d_min_pts : min_pts_imm;
+    const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
     uint64_t lo, hi;
     m.window(i, lo, hi);
     int cnt = 0;
-    for (uint64_t j = i; j < n && (uint64_t)m.key(j) <= hi; j++) cnt += m.nb(i, j);
-    for (uint64_t j = i; j-- > 0 && (uint64_t)m.key(j) >= lo;) cnt += m.nb(i, j);
+    for (uint64_t j = i; j < s1 && (uint64_t)m.key(j) <= hi; j++) cnt += m.nb(i, j);
+    for (uint64_t j = i; j-- > s0 && (uint64_t)m.key(j) >= lo;) cnt += m.nb(i, j);
     core[i] = cnt >= min_pts;
 }
 
@@ -101,22 +110,16 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
     }
 }
 
-__global__ void db_init_parent_kernel(uint32_t *parent, uint32_t *is_root, uint64_t n)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { parent[i] = (uint32_t)i; is_root[i] = 0; }
-    if (i == n) is_root[n] = 0;
-}
-
 template <class M>
-__global__ void db_union_kernel(M m, uint64_t n, const uint8_t *__restrict__ core, const uint32_t *__restrict__ oid, uint32_t *parent)
+__global__ void db_union_kernel(M m, uint64_t n, uint64_t split, const uint8_t *__restrict__ core, const uint32_t *__restrict__ oid, uint32_t *parent)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !core[i]) return;
     uint64_t lo, hi;
     m.window(i, lo, hi);
+    const uint64_t s1 = i < split ? split : n;
     const uint32_t me = oid ? oid[i] : (uint32_t)i;
-    for (uint64_t j = i + 1; j < n && (uint64_t)m.key(j) <= hi; j++)
+    for (uint64_t j = i + 1; j < s1 && (uint64_t)m.key(j) <= hi; j++)
         if (core[j] && m.nb(i, j)) uf_union(parent, me, oid ? oid[j] : (uint32_t)j);
 }
 
@@ -134,25 +137,30 @@ __global__ void db_roots_kernel(uint64_t n, const uint8_t *__restrict__ core, co
 }
 
 template <class M>
-__global__ void db_label_kernel(M m, uint64_t n, const uint32_t *__restrict__ oid, const uint32_t *__restrict__ root_of,
-                                const uint32_t *__restrict__ cid, int32_t *__restrict__ labels)
+__global__ void db_label_kernel(M m, uint64_t n, uint64_t split, const uint32_t *__restrict__ oid, const uint32_t *__restrict__ root_of,
+                                const uint32_t *__restrict__ cid_raw, int32_t *__restrict__ labels)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t me = oid ? oid[i] : (uint32_t)i;
     const uint32_t r = root_of[i];
+    // ids of the second set restart at 0: subtract the number of roots of the first set (only used with oid == nullptr,
+    // where original index == position, so cid_raw[split] is that count)
+    const uint32_t id0 = (i >= split && split < n) ? cid_raw[split] : 0u;
+    const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
+    struct { const uint32_t *p; uint32_t off; __device__ uint32_t operator[](uint32_t k) const { return p[k] - off; } } cid{cid_raw, id0};
     if (r != NONE) { labels[me] = (int32_t)cid[r]; return; }
     uint64_t lo, hi;
     m.window(i, lo, hi);
     int32_t max_start = -1, min_core = INT32_MAX;
-    for (uint64_t j = i + 1; j < n && (uint64_t)m.key(j) <= hi; j++) {
+    for (uint64_t j = i + 1; j < s1 && (uint64_t)m.key(j) <= hi; j++) {
         const uint32_t rj = root_of[j];
         if (rj != NONE && m.nb(i, j)) {
             const int32_t c = (int32_t)cid[rj];
             if (rj == (oid ? oid[j] : (uint32_t)j)) max_start = max(max_start, c); else min_core = min(min_core, c);
         }
     }
-    for (uint64_t j = i; j-- > 0 && (uint64_t)m.key(j) >= lo;) {
+    for (uint64_t j = i; j-- > s0 && (uint64_t)m.key(j) >= lo;) {
         const uint32_t rj = root_of[j];
         if (rj != NONE && m.nb(i, j)) {
             const int32_t c = (int32_t)cid[rj];
@@ -169,7 +177,7 @@ size_t dbscan_tmp_bytes(uint64_t n)
 }
 
 template <class M>
-static void run_dbscan(hipStream_t s, M m, const uint32_t *oid, uint64_t n, int min_pts, const int *d_min_pts,
+static void run_dbscan(hipStream_t s, M m, const uint32_t *oid, uint64_t n, uint64_t split, int min_pts, const int *d_min_pts,
                        int32_t *labels, void *tmp)
 {
     if (n == 0) return;
@@ -180,19 +188,18 @@ static void run_dbscan(hipStream_t s, M m, const uint32_t *oid, uint64_t n, int 
     uint32_t *cid = (uint32_t *)p;     p += align_up((n + 1) * 4, 256);
     void *es_tmp = p;
     const dim3 grid((unsigned)((n + 255) / 256)), grid1((unsigned)((n + 1 + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(db_init_parent_kernel, grid1, blk, 0, s, parent, cid, n);
-    hipLaunchKernelGGL(db_count_kernel<M>, grid, blk, 0, s, m, n, min_pts, d_min_pts, core);
-    hipLaunchKernelGGL(db_union_kernel<M>, grid, blk, 0, s, m, n, core, oid, parent);
+    hipLaunchKernelGGL(db_count_kernel<M>, grid1, blk, 0, s, m, n, split, min_pts, d_min_pts, oid, core, parent, cid);
+    hipLaunchKernelGGL(db_union_kernel<M>, grid, blk, 0, s, m, n, split, core, oid, parent);
     hipLaunchKernelGGL(db_roots_kernel, grid, blk, 0, s, n, core, oid, parent, root_of, cid);
     launch_exclusive_sum_u32(s, cid, n + 1, es_tmp);
-    hipLaunchKernelGGL(db_label_kernel<M>, grid, blk, 0, s, m, n, oid, root_of, cid, labels);
+    hipLaunchKernelGGL(db_label_kernel<M>, grid, blk, 0, s, m, n, split, oid, root_of, cid, labels);
 }
 
 void launch_dbscan_iv_sorted(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint32_t *oid,
-                             uint64_t n, double eps, int min_pts, const int *d_min_pts, int32_t *labels, void *tmp)
+                             uint64_t n, uint64_t split, double eps, int min_pts, const int *d_min_pts, int32_t *labels, void *tmp)
 {
     IntervalMetric m{start, end, eps};
-    run_dbscan(s, m, oid, n, min_pts, d_min_pts, labels, tmp);
+    run_dbscan(s, m, oid, n, oid ? n : split, min_pts, d_min_pts, labels, tmp);
 }
 
 size_t dbscan1d_big_tmp_bytes(uint64_t n) { return dbscan_tmp_bytes(n); }
@@ -201,7 +208,7 @@ void launch_dbscan_1d_big(hipStream_t s, const int32_t *pts_sorted, const uint32
                           int min_pts, int32_t *labels, void *tmp)
 {
     PointMetric m{pts_sorted, eps};
-    run_dbscan(s, m, oid, n, min_pts, nullptr, labels, tmp);
+    run_dbscan(s, m, oid, n, n, min_pts, nullptr, labels, tmp);
 }
 
 }  // namespace csv

@@ -10,8 +10,9 @@
 // Radix sort: 8-bit digits, one 64-lane wave owns a tile of 2048 keys and walks it in 32 rounds of
 // 64 (round-major = index order). Ranks inside a round come from an 8-ballot match-any, per-digit
 // running offsets live in the wave's private 1 KiB of LDS, so the scatter is stable without any
-// workgroup barrier. Three small kernels per pass: histogram, exclusive scan of the (digit, tile)
-// table, scatter. Only as many passes as the keys have bits.
+// workgroup barrier. Three small kernels per pass: histogram, single-workgroup exclusive scan of the
+// (digit, tile) table, scatter. Only as many passes as the keys have bits (41-bit keys: 6 passes;
+// 11-bit digits were measured slower: 2x the time in table traffic for 2 passes less).
 #include "../common.hpp"
 #include "../devutil.hpp"
 
@@ -20,8 +21,9 @@ namespace csv {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / WAVE;
 constexpr int RS_ROUNDS = 32;
-constexpr int RS_TILE = RS_ROUNDS * WAVE;     // 2048 keys per wave
-constexpr int RS_BINS = 256;
+
+constexpr int RS_BITS = 8;                    // digit width
+constexpr int RS_BINS = 1 << RS_BITS;         // 256 digit cursors per wave = 1 KiB of LDS
 
 // ------------------------------------------------------------------------------- generic exclusive sum (u32)
 constexpr int ES_THREADS = 256;
@@ -86,11 +88,47 @@ __global__ __launch_bounds__(ES_THREADS) void es_down_kernel(uint32_t *__restric
     }
 }
 
+// one workgroup scans the whole array in 16 Ki-entry chunks staged through LDS (coalesced loads and stores; each
+// thread scans 16 consecutive LDS entries, the 1024 run totals go through a DPP wave scan). One launch instead of
+// three — these tables are a few thousand to a few hundred thousand entries, where latency, not bandwidth, is the cost.
+constexpr int ES1_THREADS = 1024;
+constexpr int ES1_PER = 16;                        // entries per thread per chunk
+constexpr int ES1_CHUNK = ES1_THREADS * ES1_PER;   // 16384 entries (64 KiB of LDS) per chunk
+constexpr uint64_t ES1_MAX = 1ull << 21;
+__global__ __launch_bounds__(ES1_THREADS) void es_single_kernel(uint32_t *__restrict__ data, uint64_t n)
+{
+    __shared__ uint32_t buf[ES1_CHUNK + ES1_CHUNK / 32];   // +1 word of padding every 32: the per-thread runs stay conflict-light
+    __shared__ uint32_t ws[ES1_THREADS / WAVE];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    for (uint64_t c0 = 0; c0 < n; c0 += ES1_CHUNK) {
+        const uint32_t cn = (uint32_t)min((uint64_t)ES1_CHUNK, n - c0);
+        for (uint32_t i = threadIdx.x; i < cn; i += ES1_THREADS) buf[i + (i >> 5)] = data[c0 + i];      // coalesced in
+        __syncthreads();
+        const uint32_t b0 = threadIdx.x * ES1_PER;
+        uint32_t v[ES1_PER], m = 0;
+#pragma unroll
+        for (int k = 0; k < ES1_PER; k++) { const uint32_t i = b0 + k; v[k] = i < cn ? buf[i + (i >> 5)] : 0u; m += v[k]; }
+        const uint32_t inc = wave_incl_sum_dpp(m);
+        if (lane_id() == 63) ws[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t pre = carry_s + inc - m;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pre += ws[w];
+#pragma unroll
+        for (int k = 0; k < ES1_PER; k++) { const uint32_t i = b0 + k; if (i < cn) buf[i + (i >> 5)] = pre; pre += v[k]; }
+        __syncthreads();
+        if (threadIdx.x == ES1_THREADS - 1) carry_s = pre;
+        for (uint32_t i = threadIdx.x; i < cn; i += ES1_THREADS) data[c0 + i] = buf[i + (i >> 5)];      // coalesced out
+        __syncthreads();
+    }
+}
+
 size_t exclusive_sum_tmp_bytes(uint64_t n) { return align_up(((n + ES_TILE - 1) / ES_TILE + 1) * sizeof(uint32_t), 256); }
 
 void launch_exclusive_sum_u32(hipStream_t s, uint32_t *data, uint64_t n, void *tmp)
 {
     if (n == 0) return;
+    if (n <= ES1_MAX) { hipLaunchKernelGGL(es_single_kernel, dim3(1), dim3(ES1_THREADS), 0, s, data, n); return; }
     const uint64_t nb = (n + ES_TILE - 1) / ES_TILE;
     uint32_t *blk = (uint32_t *)tmp;
     hipLaunchKernelGGL(es_reduce_kernel, dim3((unsigned)nb), dim3(ES_THREADS), 0, s, data, n, blk);
@@ -100,7 +138,7 @@ void launch_exclusive_sum_u32(hipStream_t s, uint32_t *data, uint64_t n, void *t
 
 // ------------------------------------------------------------------------------- radix sort passes
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n, int shift,
-                                                            uint32_t *__restrict__ table, uint32_t n_tiles)
+                                                            uint32_t *__restrict__ table, uint32_t n_tiles, int rounds)
 {
     __shared__ uint32_t hist[RS_WAVES][RS_BINS];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -108,10 +146,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__r
     for (int b = lane; b < RS_BINS; b += WAVE) hist[wave][b] = 0;
     __builtin_amdgcn_wave_barrier();
     if (tile < n_tiles) {
-        const uint64_t t0 = tile * RS_TILE;
-        for (int rd = 0; rd < RS_ROUNDS; rd++) {
+        const uint64_t t0 = tile * (uint64_t)rounds * WAVE;
+        for (int rd = 0; rd < rounds; rd++) {
             const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
-            if (i < n) atomicAdd(&hist[wave][(keys[i] >> shift) & 0xff], 1u);
+            if (i < n) atomicAdd(&hist[wave][(keys[i] >> shift) & (RS_BINS - 1)], 1u);
         }
         __builtin_amdgcn_wave_barrier();
         for (int b = lane; b < RS_BINS; b += WAVE) table[(uint64_t)b * n_tiles + tile] = hist[wave][b];
@@ -120,7 +158,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__r
 
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                                uint64_t n, int shift, const uint32_t *__restrict__ table,
-                                                               uint32_t n_tiles, uint64_t *__restrict__ keys_out,
+                                                               uint32_t n_tiles, int rounds, uint64_t *__restrict__ keys_out,
                                                                uint32_t *__restrict__ vals_out)
 {
     __shared__ uint32_t offs[RS_WAVES][RS_BINS];
@@ -129,18 +167,18 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     if (tile >= n_tiles) return;
     for (int b = lane; b < RS_BINS; b += WAVE) offs[wave][b] = table[(uint64_t)b * n_tiles + tile];
     __builtin_amdgcn_wave_barrier();
-    const uint64_t t0 = tile * RS_TILE;
+    const uint64_t t0 = tile * (uint64_t)rounds * WAVE;
     const uint64_t lt = lanemask_lt();
-    for (int rd = 0; rd < RS_ROUNDS; rd++) {
+    for (int rd = 0; rd < rounds; rd++) {
         const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
         const bool valid = i < n;
         uint64_t key = 0; uint32_t val = 0;
         if (valid) { key = keys_in[i]; val = vals_in[i]; }
-        const uint32_t d = (uint32_t)(key >> shift) & 0xffu;
+        const uint32_t d = (uint32_t)(key >> shift) & (uint32_t)(RS_BINS - 1);
         uint64_t mask = __ballot(valid);
         if (mask == 0) break;
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < RS_BITS; b++) {
             const bool bit = (d >> b) & 1u;
             const uint64_t bal = __ballot(bit);
             mask &= bit ? bal : ~bal;
@@ -156,9 +194,18 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     }
 }
 
+// keys per wave-tile: small inputs get small tiles so that the pass still fills the chip with waves
+static int rs_rounds_for(uint64_t n)
+{
+    int rounds = RS_ROUNDS;
+    // fewer keys per tile = more waves but a larger (digit, tile) table to scan: ~128 tiles is the measured sweet spot
+    while (rounds > 2 && (n + (uint64_t)rounds * WAVE - 1) / ((uint64_t)rounds * WAVE) < 128) rounds >>= 1;
+    return rounds;
+}
+
 size_t radix_sort_tmp_bytes(uint64_t n)
 {
-    const uint64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
+    const uint64_t n_tiles = (n + 2 * WAVE - 1) / (2 * WAVE);         // upper bound (smallest tile)
     const uint64_t tab = (uint64_t)RS_BINS * (n_tiles ? n_tiles : 1);
     return align_up(tab * sizeof(uint32_t), 256) + exclusive_sum_tmp_bytes(tab);
 }
@@ -167,19 +214,21 @@ int launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, u
                           uint64_t n, int key_bits, void *tmp)
 {
     if (n <= 1 || key_bits <= 0) return 0;
-    const uint32_t n_tiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    const int rounds = rs_rounds_for(n);
+    const uint64_t tile_keys = (uint64_t)rounds * WAVE;
+    const uint32_t n_tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
     const uint64_t tab = (uint64_t)RS_BINS * n_tiles;
     uint32_t *table = (uint32_t *)tmp;
     void *es_tmp = (char *)tmp + align_up(tab * sizeof(uint32_t), 256);
     const unsigned grid = (n_tiles + RS_WAVES - 1) / RS_WAVES;
-    const int passes = (key_bits + 7) / 8;
+    const int passes = (key_bits + RS_BITS - 1) / RS_BITS;
     uint64_t *ki = keys_in, *ko = keys_out;
     uint32_t *vi = vals_in, *vo = vals_out;
     for (int p = 0; p < passes; p++) {
-        const int shift = p * 8;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, n, shift, table, n_tiles);
+        const int shift = p * RS_BITS;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, n, shift, table, n_tiles, rounds);
         launch_exclusive_sum_u32(s, table, tab, es_tmp);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, vi, n, shift, table, n_tiles, ko, vo);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, vi, n, shift, table, n_tiles, rounds, ko, vo);
         uint64_t *tk = ki; ki = ko; ko = tk;
         uint32_t *tv = vi; vi = vo; vo = tv;
     }
@@ -187,16 +236,18 @@ int launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, u
 }
 
 // ------------------------------------------------------------------------------- signature ordering
-// key = [type bit | start | end-start]; type bit 0 = DEL, 1 = INS so the DEL calls come first
-// (mergeSVs walks DEL, DUP, INV, INS, BND — sv_object.cpp:62-68). type_bit_pos < 0: no type bit
-// (the interleaved order of the reference's single chr_sv_calls vector).
+// key = [type bit | start]; type bit 0 = DEL, 1 = INS so the DEL calls come first (mergeSVs walks DEL, DUP, INV,
+// INS, BND — sv_object.cpp:62-68). type_bit_pos < 0: no type bit (the interleaved order of the reference's single
+// chr_sv_calls vector). The END is not part of the radix key: calls sharing a start are few (the local coverage at
+// most), so (end, reverse insertion) is settled by the rank pass below and the sort needs 2 passes less.
 __global__ void sig_make_keys_kernel(const csv_sig *__restrict__ sig, uint64_t n, int len_bits, int type_bit_pos,
                                      uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const csv_sig s = sig[i];
-    uint64_t k = ((uint64_t)s.start << len_bits) | (uint64_t)(s.end - s.start);
+    (void)len_bits;
+    uint64_t k = (uint64_t)s.start;
     if (type_bit_pos >= 0 && (s.qpos_kind & 3u) != CSV_KIND_DEL) k |= 1ull << type_bit_pos;
     keys[i] = k;
     vals[i] = (uint32_t)i;
@@ -209,8 +260,8 @@ void launch_sig_make_keys(hipStream_t s, const csv_sig *sig, uint64_t n, int len
     hipLaunchKernelGGL(sig_make_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sig, n, len_bits, type_bit_pos, keys, vals);
 }
 
-// Inside a run of equal keys the reference order is reverse insertion order: later read first, and
-// within one read the later CIGAR op (larger query offset) first. Each thread ranks its element
+// Inside a run of equal (type, start) the reference order is: end ascending, then reverse insertion order — later
+// read first, and within one read the later CIGAR op (larger query offset) first. Each thread ranks its element
 // inside its run (runs are as long as the local coverage at most) and writes the final record.
 __global__ void sig_fix_ties_gather_kernel(const csv_sig *__restrict__ sig_raw, const uint64_t *__restrict__ keys,
                                            const uint32_t *__restrict__ vals, uint64_t n, csv_sig *__restrict__ sig_sorted,
@@ -230,7 +281,8 @@ __global__ void sig_fix_ties_gather_kernel(const csv_sig *__restrict__ sig_raw, 
         uint64_t rank = 0;
         for (uint64_t j = a; j < b; j++) {
             const csv_sig o = sig_raw[vals[j]];
-            rank += (((uint64_t)o.read << 32) | o.qpos_kind) > mine;
+            // o precedes me: smaller end, or equal end and inserted later
+            rank += (o.end < me.end) || (o.end == me.end && (((uint64_t)o.read << 32) | o.qpos_kind) > mine);
         }
         pos = a + rank;
     }
