@@ -707,6 +707,18 @@ void csvgpu_shard_free(csv_ctx *ctx, csv_shard *sh)
     shard_release(sh);
 }
 
+int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *sh, const csv_chr_result *res, csv_sig *host_sig, int32_t *host_labels)
+{
+    if (!ctx || !sh || !res) return CSV_EINVAL;
+    if (res->n_sig == 0) return CSV_OK;
+    if (!host_sig || !host_labels) { ctx->err = "chr_fetch: null output"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    CSV_HIP(ctx, hipMemcpyAsync(host_sig, res->sig_del, res->n_sig * sizeof(csv_sig), hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipMemcpyAsync(host_labels, res->label_del, res->n_sig * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
 int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
 {
     if (!ctx || (bytes && (!host_dst || !dev_src))) return CSV_EINVAL;

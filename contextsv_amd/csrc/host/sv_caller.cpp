@@ -92,9 +92,7 @@ void SVCaller::runDeviceChain(const std::string &chr, csv_shard *shard, double e
     out.sig.resize(res.n_sig);
     out.lab.resize(res.n_sig);
     out.n_del = res.n_del; out.n_ins = res.n_ins;
-    // sig_del/sig_ins and label_del/label_ins are adjacent in the shard's scratch: one copy each
-    check(ctx, csvgpu_download(ctx, out.sig.data(), res.sig_del, res.n_sig * sizeof(csv_sig)), "download signatures");
-    check(ctx, csvgpu_download(ctx, out.lab.data(), res.label_del, res.n_sig * sizeof(int32_t)), "download labels");
+    check(ctx, csvgpu_chr_fetch(ctx, shard, &res, out.sig.data(), out.lab.data()), "fetch signatures + labels");
     st.ms_device = now_ms() - t0;
 }
 

@@ -137,6 +137,26 @@ __device__ __forceinline__ ReadMd depth_load_md(uint64_t kk, uint64_t k_hi, cons
     return m;
 }
 
+// first index i in [0, n] with a[i] >= target (a non-decreasing); 64-ary search by one wave
+__device__ __forceinline__ uint64_t wave_first_ge_i32(const int32_t *__restrict__ a, uint64_t n, int64_t target, int lane)
+{
+    uint64_t lo = 0, hi = n;
+    while (hi > lo) {
+        const uint64_t span = hi - lo;
+        const uint64_t step = (span + 63) / 64;
+        const uint64_t probe = lo + (uint64_t)lane * step;
+        const bool ge = probe >= hi || (int64_t)a[probe] >= target;
+        const uint64_t m = __ballot(ge);
+        const int first_ge = m ? __ffsll((long long)m) - 1 : 64;
+        if (first_ge == 0) return lo;
+        const uint64_t new_hi = first_ge < 64 ? min(lo + (uint64_t)first_ge * step, hi) : hi;
+        lo = lo + (uint64_t)(first_ge - 1) * step + 1;
+        hi = new_hi;
+        if (step == 1) return hi;
+    }
+    return lo;
+}
+
 __device__ __forceinline__ uint32_t depth_grab(unsigned int *counter, int lane)
 {
     uint32_t v = 0;
@@ -175,19 +195,18 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     const uint64_t T1 = min(T0 + (uint64_t)DEPTH_TILE, (uint64_t)depth_len);
 
     for (int i = threadIdx.x; i < DEPTH_TILE + 4; i += DEPTH_THREADS) diff[i] = 0;
-    if (threadIdx.x == 0) {
-        next_read = 0;
-        // reads cover 1-based positions [pos+1, ref_end]; candidates: pmax_end >= T0 and pos+1 < T1
-        uint64_t lo = 0, hi = n_reads;
-        while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if ((int64_t)pmax_end[mid] >= (int64_t)T0) hi = mid; else lo = mid + 1; }
-        range_s[0] = lo;
-        uint64_t lo2 = lo; hi = n_reads;
-        while (lo2 < hi) { uint64_t mid = (lo2 + hi) >> 1; if ((int64_t)pos_s[mid] + 1 >= (int64_t)T1) hi = mid; else lo2 = mid + 1; }
-        range_s[1] = lo2;
-        blk_sum = 0; blk_nz = 0;
+    // reads cover 1-based positions [pos+1, ref_end]; candidates: pmax_end >= T0 and pos+1 < T1. Both bounds are found by
+    // 64-ary searches, one per wave, three dependent loads each (a one-thread binary search would hold the whole
+    // workgroup at this barrier for ~17 load latencies).
+    if (wave == 0) {
+        const uint64_t lo = wave_first_ge_i32(pmax_end, n_reads, (int64_t)T0, lane);
+        if (lane == 0) { range_s[0] = lo; next_read = 0; blk_sum = 0; blk_nz = 0; }
+    } else if (wave == 1) {
+        const uint64_t hi = wave_first_ge_i32(pos_s, n_reads, (int64_t)T1 - 1, lane);
+        if (lane == 0) range_s[1] = hi;
     }
     __syncthreads();
-    const uint64_t k_lo = range_s[0], k_hi = range_s[1];
+    const uint64_t k_lo = range_s[0], k_hi = max(range_s[0], range_s[1]);
 
     // reads are handed to the waves through an LDS counter (their cost varies a lot: most candidates end left of the
     // tile and are skipped, long ones take many chunks), with the next read's metadata already in flight

@@ -223,6 +223,10 @@ typedef struct csv_chr_result {
 int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, uint8_t min_mapq,
                             double eps, double min_pts_pct, csv_chr_result *result);
 
+/* Copy the signatures (sig_del followed by sig_ins: n_sig records) and their labels (label_del followed by
+ * label_ins) of the last csvgpu_chr_pipeline_dev() on `shard` to host memory with one synchronisation. */
+int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *shard, const csv_chr_result *result, csv_sig *host_sig, int32_t *host_labels);
+
 /* Copy `bytes` from device memory returned by this library (csv_chr_result pointers) to host memory;
  * synchronous with respect to the context's stream. For host code above the ABI that does not link HIP. */
 int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
