@@ -707,6 +707,45 @@ void csvgpu_shard_free(csv_ctx *ctx, csv_shard *sh)
     shard_release(sh);
 }
 
+int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *region_start, const uint32_t *region_end,
+                                const int32_t *sample_size, const uint64_t *win_off, uint64_t n_regions, double mean_cov,
+                                double *log2_cov, uint32_t *win_start, uint32_t *win_end)
+{
+    if (!ctx || !sh) return CSV_EINVAL;
+    if (n_regions == 0) return CSV_OK;
+    if (!region_start || !region_end || !sample_size || !win_off) { ctx->err = "window_log2: null array"; return CSV_EINVAL; }
+    for (uint64_t r = 0; r < n_regions; r++) {
+        if (sample_size[r] <= 0 || win_off[r + 1] - win_off[r] != (uint64_t)sample_size[r] || region_start[r] > region_end[r]) {
+            ctx->err = "window_log2: bad region table"; return CSV_EINVAL;
+        }
+    }
+    const uint64_t nw = win_off[n_regions];
+    if (nw == 0) return CSV_OK;
+    if (!log2_cov || !win_start || !win_end) { ctx->err = "window_log2: null output"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    int rc = arena_reserve(ctx, ctx->arena, 3 * align_up(n_regions * 4, 256) + align_up((n_regions + 1) * 8, 256) + align_up(nw * 8, 256) +
+                                                2 * align_up(nw * 4, 256) + 4096);
+    if (rc) return rc;
+    Arena &a = ctx->arena;
+    uint32_t *drs = (uint32_t *)arena_alloc(a, n_regions * 4), *dre = (uint32_t *)arena_alloc(a, n_regions * 4);
+    int32_t *dss = (int32_t *)arena_alloc(a, n_regions * 4);
+    uint64_t *dwo = (uint64_t *)arena_alloc(a, (n_regions + 1) * 8);
+    double *dl2 = (double *)arena_alloc(a, nw * 8);
+    uint32_t *dws = (uint32_t *)arena_alloc(a, nw * 4), *dwe = (uint32_t *)arena_alloc(a, nw * 4);
+    if (!drs || !dre || !dss || !dwo || !dl2 || !dws || !dwe) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    hipStream_t s = ctx->stream;
+    CSV_HIP(ctx, hipMemcpyAsync(drs, region_start, n_regions * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(dre, region_end, n_regions * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(dss, sample_size, n_regions * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(dwo, win_off, (n_regions + 1) * 8, hipMemcpyHostToDevice, s));
+    if ((rc = csvgpu_window_log2_dev(ctx, sh->depth, sh->depth_len, drs, dre, dss, dwo, n_regions, nw, mean_cov, dl2, dws, dwe))) return rc;
+    CSV_HIP(ctx, hipMemcpyAsync(log2_cov, dl2, nw * 8, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipMemcpyAsync(win_start, dws, nw * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipMemcpyAsync(win_end, dwe, nw * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipStreamSynchronize(s));
+    return CSV_OK;
+}
+
 int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *sh, const csv_chr_result *res, csv_sig *host_sig, int32_t *host_labels)
 {
     if (!ctx || !sh || !res) return CSV_EINVAL;

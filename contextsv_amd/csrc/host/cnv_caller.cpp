@@ -1,0 +1,240 @@
+#include "cnv_caller.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+#include "log.h"
+
+namespace {
+void check(csv_ctx *ctx, int rc, const char *what)
+{
+    if (rc != CSV_OK) throw std::runtime_error(std::string(what) + ": " + csvgpu_last_error(ctx));
+}
+}  // namespace
+
+void SNPTable::query(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos, std::unordered_map<uint32_t, double> &snp_baf,
+                     std::unordered_map<uint32_t, double> &snp_pfb) const
+{
+    const size_t a = std::lower_bound(pos.begin(), pos.end(), start_pos) - pos.begin();
+    for (size_t i = a; i < pos.size() && pos[i] <= end_pos; i++) {
+        snp_pos.push_back(pos[i]);
+        snp_baf[pos[i]] = baf[i];
+        if (!has_pfb.empty() && has_pfb[i]) snp_pfb[pos[i]] = pfb[i];
+    }
+}
+
+Genotype CNVCaller::getGenotypeFromCNState(int cn_state)
+{
+    switch (cn_state) {
+        case 0: return Genotype::UNKNOWN;
+        case 1: case 4: case 6: return Genotype::HOMOZYGOUS_ALT;
+        case 2: case 5: return Genotype::HETEROZYGOUS;
+        case 3: return Genotype::HOMOZYGOUS_REF;
+    }
+    printError("ERROR: Invalid CN state: " + std::to_string(cn_state));
+    return Genotype::UNKNOWN;
+}
+
+void CNVCaller::querySNPRegions(const std::vector<std::pair<uint32_t, uint32_t>> &regions, csv_shard *shard, double mean_chr_cov,
+                                const SNPSource &snps, std::vector<SNPData> &out) const
+{
+    const size_t n = regions.size();
+    out.assign(n, SNPData());
+    struct RegionSnps { std::vector<uint32_t> pos; std::unordered_map<uint32_t, double> baf, pfb; };
+    std::vector<RegionSnps> rs(n);
+    std::vector<uint32_t> r_start, r_end;
+    std::vector<int32_t> r_ss;
+    std::vector<uint64_t> win_off{0};
+    std::vector<size_t> slot(n, SIZE_MAX);                 // region -> row of the device batch (invalid regions have none)
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t start_pos = regions[i].first, end_pos = regions[i].second;
+        snps.query(start_pos, end_pos, rs[i].pos, rs[i].baf, rs[i].pfb);
+        if (start_pos > end_pos) {                          // the reference logs and leaves snp_data empty (cnv_caller.cpp:69-73)
+            printError("ERROR: Invalid SNP region for copy number prediction: " + std::to_string((int)start_pos) + "-" + std::to_string((int)end_pos));
+            continue;
+        }
+        const int ss = std::max((int)rs[i].pos.size(), sample_size);   // :65
+        slot[i] = r_start.size();
+        r_start.push_back(start_pos); r_end.push_back(end_pos); r_ss.push_back(ss);
+        win_off.push_back(win_off.back() + (uint64_t)ss);
+    }
+    const uint64_t nw = win_off.back();
+    std::vector<double> log2_cov(nw);
+    std::vector<uint32_t> ws(nw), we(nw);
+    if (!r_start.empty())
+        check(ctx, csvgpu_window_log2_resident(ctx, shard, r_start.data(), r_end.data(), r_ss.data(), win_off.data(), r_start.size(), mean_chr_cov,
+                                               log2_cov.data(), ws.data(), we.data()), "querySNPRegion");
+    for (size_t i = 0; i < n; i++) {
+        if (slot[i] == SIZE_MAX) continue;
+        const uint64_t w0 = win_off[slot[i]], w1 = win_off[slot[i] + 1];
+        // the reference keys the windows by the string "ws-we" in an unordered_map: equal keys collapse (later window
+        // wins) and the iteration order of that libstdc++ container is the observation order (:77, :111-112, :124)
+        std::unordered_map<std::string, double> window_log2_map;
+        for (uint64_t w = w0; w < w1; w++) window_log2_map[std::to_string(ws[w]) + "-" + std::to_string(we[w])] = log2_cov[w];
+        SNPData &d = out[i];
+        RegionSnps &r = rs[i];
+        for (const auto &window : window_log2_map) {
+            const uint32_t window_start = (uint32_t)std::stoi(window.first.substr(0, window.first.find('-')));
+            const uint32_t window_end = (uint32_t)std::stoi(window.first.substr(window.first.find('-') + 1));
+            const double l2 = window.second;
+            bool snp_found = false;
+            for (uint32_t pos : r.pos) {
+                if (pos >= window_start && pos <= window_end) {        // inclusive both ends: a SNP can land in two windows (:132)
+                    d.pos.push_back(pos); d.baf.push_back(r.baf[pos]); d.pfb.push_back(r.pfb[pos]);
+                    d.log2_cov.push_back(l2); d.is_snp.push_back(true);
+                    snp_found = true;
+                }
+            }
+            if (!snp_found) {                                           // dummy observation at the window centre (:144-155)
+                d.pos.push_back((window_start + window_end) / 2); d.baf.push_back(-1.0); d.pfb.push_back(0.5);
+                d.log2_cov.push_back(l2); d.is_snp.push_back(false);
+            }
+        }
+    }
+}
+
+void CNVCaller::runViterbi(const CHMM &hmm, const std::vector<SNPData> &data, std::vector<std::pair<std::vector<int>, double>> &predictions) const
+{
+    VitBatch b;
+    for (const SNPData &d : data) b.add(d.log2_cov, d.baf, d.pfb);
+    std::vector<int> states;
+    std::vector<double> ll;
+    testVit_CHMM_batch(hmm, b, states, ll);
+    predictions.resize(data.size());
+    for (size_t i = 0; i < data.size(); i++) {
+        if (data[i].pos.empty()) {                                      // runViterbi logs and still calls testVit_CHMM with T = 0 (:43-49)
+            printError("ERROR: No SNP data found for Viterbi algorithm.");
+            predictions[i] = std::make_pair(std::vector<int>(), ll[i]);
+            continue;
+        }
+        predictions[i] = std::make_pair(std::vector<int>(states.begin() + b.seq_off[i], states.begin() + b.seq_off[i + 1]), ll[i]);
+    }
+}
+
+void CNVCaller::runCIGARCopyNumberPrediction(const std::string &chr, std::vector<SVCall> &sv_candidates, const CHMM &hmm, double mean_chr_cov,
+                                             csv_shard *shard, const SNPSource &snps) const
+{
+    std::vector<size_t> idx;
+    std::vector<std::pair<uint32_t, uint32_t>> regions;
+    for (size_t k = 0; k < sv_candidates.size(); k++) {
+        const SVCall &c = sv_candidates[k];
+        if (c.start > c.end) {
+            printError("ERROR: Invalid SV region for copy number prediction: " + chr + ":" + std::to_string((int)c.start) + "-" + std::to_string((int)c.end));
+            continue;
+        }
+        if ((c.end - c.start) < min_cnv_length) continue;               // :315
+        idx.push_back(k); regions.emplace_back(c.start, c.end);
+    }
+    if (idx.empty()) return;
+    std::vector<SNPData> data;
+    querySNPRegions(regions, shard, mean_chr_cov, snps, data);
+    std::vector<std::pair<std::vector<int>, double>> pred;
+    runViterbi(hmm, data, pred);
+    for (size_t q = 0; q < idx.size(); q++) {
+        SVCall &sv_call = sv_candidates[idx[q]];
+        const SNPData &snp_data = data[q];
+        if (snp_data.pos.empty()) {
+            printError("ERROR: No SNP data found for Viterbi algorithm for CIGAR SV at " + chr + ":" + std::to_string((int)sv_call.start) + "-" + std::to_string((int)sv_call.end));
+            continue;
+        }
+        const std::vector<int> &state_sequence = pred[q].first;
+        const double likelihood = pred[q].second;
+        int counts[7] = {0, 0, 0, 0, 0, 0, 0}, n_in = 0;                // states of observations inside [start,end] (:337-346)
+        for (size_t i = 0; i < state_sequence.size(); i++)
+            if (snp_data.pos[i] >= sv_call.start && snp_data.pos[i] <= sv_call.end) { counts[state_sequence[i]]++; n_in++; }
+        int max_state = 0, max_count = 0;                                // first maximum wins (:350-360)
+        for (int s = 1; s <= 6; s++) if (counts[s] > max_count) { max_state = s; max_count = counts[s]; }
+        if ((double)max_count / (double)n_in < 0.50) max_state = 0;      // :363-367 (0/0 -> NaN < 0.5 is false, as in the reference)
+        const Genotype genotype = getGenotypeFromCNState(max_state);
+        SVType updated = getSVTypeFromCNState(max_state);
+        updated = (updated == SVType::LOH) ? sv_call.sv_type : updated;  // :375
+        if (isValidCopyNumberUpdate(sv_call.sv_type, updated)) {
+            sv_call.sv_type = updated;
+            sv_call.aln_type.set((size_t)SVDataType::HMM);
+            sv_call.hmm_likelihood = likelihood;
+            sv_call.genotype = genotype;
+            sv_call.cn_state = max_state;
+        }
+    }
+}
+
+void CNVCaller::runCopyNumberPredictions(const std::string &chr, const CHMM &hmm, const std::vector<std::pair<uint32_t, uint32_t>> &regions,
+                                         double mean_chr_cov, csv_shard *shard, const SNPSource &snps,
+                                         std::vector<std::tuple<double, SVType, Genotype, int>> &results) const
+{
+    results.assign(regions.size(), std::make_tuple(0.0, SVType::UNKNOWN, Genotype::UNKNOWN, 0));
+    std::vector<size_t> idx;
+    std::vector<std::pair<uint32_t, uint32_t>> valid;
+    for (size_t k = 0; k < regions.size(); k++) {
+        if (regions[k].first > regions[k].second) {                      // :169-173
+            printError("ERROR: Invalid SV region for copy number prediction: " + chr + ":" + std::to_string((int)regions[k].first) + "-" + std::to_string((int)regions[k].second));
+            continue;
+        }
+        idx.push_back(k); valid.push_back(regions[k]);
+    }
+    if (idx.empty()) return;
+    std::vector<SNPData> data;
+    querySNPRegions(valid, shard, mean_chr_cov, snps, data);
+    std::vector<std::pair<std::vector<int>, double>> pred;
+    runViterbi(hmm, data, pred);
+    for (size_t q = 0; q < idx.size(); q++) {
+        const std::vector<int> &seq = pred[q].first;
+        if (seq.empty()) continue;                                       // :206-209
+        double pct[7] = {0, 0, 0, 0, 0, 0, 0};
+        const double state_count = (double)seq.size();
+        double largest_non_neutral_pct = 0.0; int non_neutral_state = 0;
+        for (int i = 0; i < 6; i++) {                                    // :214-224
+            pct[i + 1] = (double)std::count(seq.begin(), seq.end(), i + 1) / state_count;
+            if (i + 1 != 3 && pct[i + 1] > largest_non_neutral_pct) { largest_non_neutral_pct = pct[i + 1]; non_neutral_state = i + 1; }
+        }
+        int max_state = 0;
+        if (largest_non_neutral_pct > 0.3) max_state = non_neutral_state;   // :227-238
+        else if (pct[3] > 0.3) max_state = 3;
+        results[idx[q]] = std::make_tuple(pred[q].second, getSVTypeFromCNState(max_state), getGenotypeFromCNState(max_state), max_state);
+    }
+}
+
+void CNVCaller::runSplitReadCopyNumberPredictions(const std::string &chr, std::vector<SVCall> &split_sv_calls, const CHMM &hmm, double mean_chr_cov,
+                                                  csv_shard *shard, const SNPSource &snps) const
+{
+    std::vector<std::pair<uint32_t, uint32_t>> regions;
+    for (const SVCall &c : split_sv_calls) regions.emplace_back(c.start, c.end);
+    std::vector<std::tuple<double, SVType, Genotype, int>> results;
+    runCopyNumberPredictions(chr, hmm, regions, mean_chr_cov, shard, snps, results);
+
+    auto take_prediction = [](SVCall &c, double lh, Genotype g, int cn) {
+        c.aln_type.set((size_t)SVDataType::HMM); c.hmm_likelihood = lh; c.genotype = g; c.cn_state = cn;
+    };
+    std::vector<SVCall> additional_calls;
+    for (size_t k = 0; k < split_sv_calls.size(); k++) {
+        SVCall &c = split_sv_calls[k];
+        const double supp_lh = std::get<0>(results[k]);
+        const SVType supp_type = std::get<1>(results[k]);
+        const Genotype genotype = std::get<2>(results[k]);
+        const int cn_state = std::get<3>(results[k]);
+        if (supp_type == SVType::UNKNOWN) continue;
+        const bool supp_cnv = supp_type == SVType::DEL || supp_type == SVType::DUP;
+        if (c.sv_type == SVType::UNKNOWN && supp_cnv) {                                          // sv_caller.cpp:999-1005
+            c.sv_type = supp_type; c.alt_allele = getSVTypeSymbol(supp_type); take_prediction(c, supp_lh, genotype, cn_state);
+        } else if (c.sv_type != SVType::UNKNOWN && (supp_type == c.sv_type || supp_type == SVType::LOH || supp_type == SVType::NEUTRAL)) {
+            take_prediction(c, supp_lh, genotype, cn_state);                                     // :1009-1013
+        } else if (c.sv_type != SVType::UNKNOWN && supp_type != c.sv_type && supp_cnv) {
+            if (c.sv_type == SVType::INV) {                                                      // :1020-1024
+                take_prediction(c, supp_lh, genotype, cn_state);
+            } else if (c.sv_type == SVType::INS && supp_type == SVType::DUP) {                   // :1026-1032
+                c.sv_type = supp_type; c.alt_allele = getSVTypeSymbol(supp_type); take_prediction(c, supp_lh, genotype, cn_state);
+            } else {                                                                             // :1033-1043
+                SVCall extra = c;
+                extra.sv_type = supp_type; extra.alt_allele = getSVTypeSymbol(supp_type); take_prediction(extra, supp_lh, genotype, cn_state);
+                additional_calls.push_back(extra);
+            }
+        }
+    }
+    for (SVCall &extra : additional_calls) {                                                     // :1050-1063
+        bool found = false;
+        for (SVCall &existing : split_sv_calls) {
+            if (existing.start == extra.start && existing.end == extra.end && existing.sv_type == extra.sv_type) { existing = extra; found = true; break; }
+        }
+        if (!found) addSVCall(split_sv_calls, extra);
+    }
+}

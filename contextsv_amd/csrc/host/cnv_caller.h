@@ -1,0 +1,79 @@
+// cnv_caller.h — host mirror of the copy-number pass of the reference's CNVCaller / SVCaller
+// (src/cnv_caller.cpp:41-387, src/sv_caller.cpp:983-1064), batched over the device kernels:
+//   * the per-window depth sums + log2 ratios of querySNPRegion (cnv_caller.cpp:76-113) run in hmm.hip on the depth map
+//     that stays resident in the shard (csvgpu_window_log2_resident), for all SVs of a chromosome in one launch;
+//   * the observation sequences are assembled on the host exactly like the reference does — through a
+//     std::unordered_map<std::string,double> keyed "ws-we", whose libstdc++ iteration order IS the observation
+//     order (cnv_caller.cpp:77,124) — and all of them go through ONE batched Viterbi call (csvgpu_viterbi);
+//   * the state votes and SVCall update rules are the reference's, line for line in behaviour.
+// The reference re-opens and re-indexes the SNP VCF for every SV (readSNPAlleleFrequencies, cnv_caller.cpp:558-809);
+// that reader is I/O outside this path, so SNPs come from a caller-supplied SNPSource.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/csvgpu.h"
+#include "khmm.h"
+#include "sv_object.h"
+
+struct SNPData {
+    std::vector<uint32_t> pos;
+    std::vector<double> pfb;
+    std::vector<double> baf;
+    std::vector<double> log2_cov;
+    std::vector<int> state_sequence;
+    std::vector<bool> is_snp;
+    double mean_chr_cov = 0;
+};
+
+// What readSNPAlleleFrequencies hands back for one region: positions (file order) and the two hash maps.
+struct SNPSource {
+    virtual ~SNPSource() = default;
+    virtual void query(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos,
+                       std::unordered_map<uint32_t, double> &snp_baf, std::unordered_map<uint32_t, double> &snp_pfb) const = 0;
+};
+
+// SNPs of one chromosome held in sorted arrays (the one-time-per-chromosome load the reference lacks).
+// has_pfb[i] == 0 reproduces the reference's default-constructed 0.0 for SNPs without a gnomAD hit (cnv_caller.cpp:138).
+struct SNPTable : SNPSource {
+    std::vector<uint32_t> pos;
+    std::vector<double> baf, pfb;
+    std::vector<uint8_t> has_pfb;
+    void query(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos, std::unordered_map<uint32_t, double> &snp_baf,
+               std::unordered_map<uint32_t, double> &snp_pfb) const override;
+};
+
+class CNVCaller {
+public:
+    explicit CNVCaller(csv_ctx *ctx) : ctx(ctx) {}
+    int sample_size = 20;            // --sample-size (input_data.cpp:18-37)
+    uint32_t min_cnv_length = 2000;  // --min-cnv
+
+    static Genotype getGenotypeFromCNState(int cn_state);   // cnv_caller.h:76-97 of the reference
+
+    // querySNPRegion for many regions at once (one window launch); out[i] belongs to regions[i].
+    void querySNPRegions(const std::vector<std::pair<uint32_t, uint32_t>> &regions, csv_shard *shard, double mean_chr_cov,
+                         const SNPSource &snps, std::vector<SNPData> &out) const;
+
+    // runViterbi for many SNPData at once (one Viterbi launch)
+    void runViterbi(const CHMM &hmm, const std::vector<SNPData> &data, std::vector<std::pair<std::vector<int>, double>> &predictions) const;
+
+    // cnv_caller.cpp:290-387 — updates sv_candidates in place
+    void runCIGARCopyNumberPrediction(const std::string &chr, std::vector<SVCall> &sv_candidates, const CHMM &hmm, double mean_chr_cov,
+                                      csv_shard *shard, const SNPSource &snps) const;
+
+    // cnv_caller.cpp:166-287 for a batch of regions (the JSON side output of --save-cnv is not produced)
+    void runCopyNumberPredictions(const std::string &chr, const CHMM &hmm, const std::vector<std::pair<uint32_t, uint32_t>> &regions,
+                                  double mean_chr_cov, csv_shard *shard, const SNPSource &snps,
+                                  std::vector<std::tuple<double, SVType, Genotype, int>> &results) const;
+
+    // sv_caller.cpp:983-1064 — the five-way update / duplicate rule for split-read candidates
+    void runSplitReadCopyNumberPredictions(const std::string &chr, std::vector<SVCall> &split_sv_calls, const CHMM &hmm,
+                                           double mean_chr_cov, csv_shard *shard, const SNPSource &snps) const;
+
+private:
+    csv_ctx *ctx;
+};

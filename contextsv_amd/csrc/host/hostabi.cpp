@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "cnv_caller.h"
 #include "dbscan.h"
 #include "khmm.h"
 #include "log.h"
@@ -197,6 +198,63 @@ int csvhost_process_resident_pipelined(csv_ctx *ctx, csv_shard *shard, uint64_t 
                 out[i] = p;
                 if (alt_tag) alt_tag[i] = c.alt_allele == "<DEL>" ? 0 : (c.alt_allele == "<INS>" ? 1 : 2);
             }
+        }
+    })
+}
+
+// ---- copy-number pass (CNVCaller mirror) -------------------------------------------------------
+static CHMM chmm_from_pod(const csv_hmm *h)
+{
+    CHMM c; c.N = 6; c.M = 6;
+    c.A.assign(6, std::vector<double>(6)); c.B.assign(6, std::vector<double>(6, 0.0));
+    c.pi.resize(6); c.B1_mean.resize(6); c.B1_sd.resize(6); c.B2_mean.resize(5); c.B2_sd.resize(5);
+    for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) c.A[i][j] = h->A[i * 6 + j]; c.pi[i] = h->pi[i]; c.B1_mean[i] = h->B1_mean[i]; c.B1_sd[i] = h->B1_sd[i]; }
+    for (int i = 0; i < 5; i++) { c.B2_mean[i] = h->B2_mean[i]; c.B2_sd[i] = h->B2_sd[i]; }
+    c.B1_uf = h->B1_uf; c.B2_uf = h->B2_uf;
+    return c;
+}
+static SNPTable snp_table(const uint32_t *pos, const double *baf, const double *pfb, const uint8_t *has_pfb, uint64_t n)
+{
+    SNPTable t;
+    t.pos.assign(pos, pos + n); t.baf.assign(baf, baf + n); t.pfb.assign(pfb, pfb + n); t.has_pfb.assign(has_pfb, has_pfb + n);
+    return t;
+}
+
+// querySNPRegion for one region: observation arrays in the reference's order. cap = capacity of the outputs.
+int csvhost_query_snp_region(csv_ctx *ctx, csv_shard *shard, uint32_t start, uint32_t end, double mean_cov, int sample_size,
+                             const uint32_t *snp_pos, const double *snp_baf, const double *snp_pfb, const uint8_t *snp_has_pfb, uint64_t n_snp,
+                             uint32_t *pos_out, double *baf_out, double *pfb_out, double *log2_out, uint8_t *is_snp_out, uint64_t cap, uint64_t *n_out)
+{
+    GUARD({
+        CNVCaller cnv(ctx); cnv.sample_size = sample_size;
+        SNPTable t = snp_table(snp_pos, snp_baf, snp_pfb, snp_has_pfb, n_snp);
+        std::vector<SNPData> d;
+        cnv.querySNPRegions({{start, end}}, shard, mean_cov, t, d);
+        *n_out = d[0].pos.size();
+        for (size_t i = 0; i < d[0].pos.size() && i < cap; i++) {
+            pos_out[i] = d[0].pos[i]; baf_out[i] = d[0].baf[i]; pfb_out[i] = d[0].pfb[i]; log2_out[i] = d[0].log2_cov[i]; is_snp_out[i] = d[0].is_snp[i];
+        }
+    })
+}
+
+// runCIGARCopyNumberPrediction (split == 0, in place) or runSplitReadCopyNumberPredictions (split == 1, may grow the list)
+int csvhost_cn_prediction(csv_ctx *ctx, csv_shard *shard, int split, csvhost_call *calls, uint64_t n, uint64_t cap, uint64_t *n_out,
+                          const csv_hmm *hmm, double mean_cov, int sample_size, uint32_t min_cnv,
+                          const uint32_t *snp_pos, const double *snp_baf, const double *snp_pfb, const uint8_t *snp_has_pfb, uint64_t n_snp)
+{
+    GUARD({
+        csvhost::set_context(ctx);
+        CNVCaller cnv(ctx); cnv.sample_size = sample_size; cnv.min_cnv_length = min_cnv;
+        SNPTable t = snp_table(snp_pos, snp_baf, snp_pfb, snp_has_pfb, n_snp);
+        CHMM h = chmm_from_pod(hmm);
+        std::vector<SVCall> v; v.reserve(n);
+        for (uint64_t i = 0; i < n; i++) v.push_back(from_pod(calls[i]));
+        if (split) cnv.runSplitReadCopyNumberPredictions("chr", v, h, mean_cov, shard, t);
+        else cnv.runCIGARCopyNumberPrediction("chr", v, h, mean_cov, shard, t);
+        *n_out = v.size();
+        for (size_t i = 0; i < v.size() && i < cap; i++) {
+            // alt_allele carries the id for untouched calls; calls whose ALT was rewritten report id -1 (and a symbol ALT)
+            calls[i] = to_pod(v[i]);
         }
     })
 }

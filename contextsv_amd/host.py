@@ -48,6 +48,10 @@ def load() -> C.CDLL:
     lib.csvhost_process_resident_chromosome.argtypes = [_P, _P, _P, _P, C.c_double, C.c_double, _P, _P, C.c_uint64, C.POINTER(chr_stats)]
     lib.csvhost_process_resident_pipelined.argtypes = [_P, _P, C.c_uint64, _P, _P, C.c_double, C.c_double, _P, _P, C.c_uint64,
                                                        C.POINTER(chr_stats), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.csvhost_query_snp_region.argtypes = [_P, _P, C.c_uint32, C.c_uint32, C.c_double, C.c_int, _P, _P, _P, _P, C.c_uint64,
+                                             _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.csvhost_cn_prediction.argtypes = [_P, _P, C.c_int, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(_lib.csv_hmm),
+                                          C.c_double, C.c_int, C.c_uint32, _P, _P, _P, _P, C.c_uint64]
     lib.csvhost_read_chmm.argtypes = [C.c_char_p, C.POINTER(_lib.csv_hmm), C.POINTER(C.c_int32)]
     lib.csvhost_sort_select_check.argtypes = [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.csvhost_set_quiet(1)
@@ -168,6 +172,39 @@ def process_resident_pipelined(ctx: Context, shard: Shard, n_steps: int, eps: fl
                                                      tag.ctypes.data, capacity, C.byref(st), C.byref(ms), C.byref(tot)))
     n = min(st.n_calls, capacity)
     return out[:n].copy(), tag[:n].copy(), st, ms.value, tot.value
+
+
+def _snp_arrays(snps):
+    pos = np.ascontiguousarray(snps["pos"], np.uint32)
+    baf = np.ascontiguousarray(snps["baf"], np.float64)
+    pfb = np.ascontiguousarray(snps["pfb"], np.float64)
+    has = np.ascontiguousarray(snps["has_pfb"], np.uint8)
+    return pos, baf, pfb, has
+
+
+def query_snp_region(ctx: Context, shard: Shard, start: int, end: int, mean_cov: float, sample_size: int, snps: dict, cap: int = 1 << 16):
+    """CNVCaller::querySNPRegion mirror on the shard's resident depth map -> dict of observation arrays."""
+    pos, baf, pfb, has = _snp_arrays(snps)
+    o_pos = np.zeros(cap, np.uint32); o_baf = np.zeros(cap); o_pfb = np.zeros(cap); o_l2 = np.zeros(cap); o_is = np.zeros(cap, np.uint8)
+    n = C.c_uint64(0)
+    _check(load().csvhost_query_snp_region(ctx.h, shard.h, start, end, mean_cov, sample_size, pos.ctypes.data, baf.ctypes.data, pfb.ctypes.data,
+                                           has.ctypes.data, len(pos), o_pos.ctypes.data, o_baf.ctypes.data, o_pfb.ctypes.data, o_l2.ctypes.data,
+                                           o_is.ctypes.data, cap, C.byref(n)))
+    k = n.value
+    return {"pos": o_pos[:k], "baf": o_baf[:k], "pfb": o_pfb[:k], "log2_cov": o_l2[:k], "is_snp": o_is[:k].astype(bool)}
+
+
+def cn_prediction(ctx: Context, shard: Shard, calls: np.ndarray, hmm, mean_cov: float, snps: dict, split: bool, sample_size: int = 20,
+                  min_cnv: int = 2000) -> np.ndarray:
+    """runCIGARCopyNumberPrediction (split=False) / runSplitReadCopyNumberPredictions (split=True) mirror."""
+    pos, baf, pfb, has = _snp_arrays(snps)
+    cap = 2 * len(calls) + 16
+    buf = np.zeros(cap, CALL_DTYPE)
+    buf[: len(calls)] = np.ascontiguousarray(calls, CALL_DTYPE)
+    n = C.c_uint64(0)
+    _check(load().csvhost_cn_prediction(ctx.h, shard.h, int(split), buf.ctypes.data, len(calls), cap, C.byref(n), C.byref(hmm), mean_cov,
+                                        sample_size, min_cnv, pos.ctypes.data, baf.ctypes.data, pfb.ctypes.data, has.ctypes.data, len(pos)))
+    return buf[: n.value].copy()
 
 
 def sort_select_check(keys: np.ndarray, nth: int):

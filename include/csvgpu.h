@@ -227,6 +227,12 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, 
  * label_ins) of the last csvgpu_chr_pipeline_dev() on `shard` to host memory with one synchronisation. */
 int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *shard, const csv_chr_result *result, csv_sig *host_sig, int32_t *host_labels);
 
+/* csvgpu_window_log2 on the depth map that the last csvgpu_chr_pipeline_dev() left resident in `shard`
+ * (region tables and outputs are host memory; the depth map never leaves HBM). */
+int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *region_start, const uint32_t *region_end,
+                                const int32_t *sample_size, const uint64_t *win_off, uint64_t n_regions, double mean_cov,
+                                double *log2_cov, uint32_t *win_start, uint32_t *win_end);
+
 /* Copy `bytes` from device memory returned by this library (csv_chr_result pointers) to host memory;
  * synchronous with respect to the context's stream. For host code above the ABI that does not link HIP. */
 int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);

@@ -107,6 +107,41 @@ class Oracle:
         self.lib.orc_viterbi_batch(C.byref(h), _p(o1), _p(o2), _p(pfb), _p(seq_off), len(seq_off) - 1, _p(st), _p(ll))
         return st[: len(o1)], ll[: len(seq_off) - 1]
 
+    # ---- copy-number pass (oracle/cnv_oracle.cpp); calls use the 48-byte layout of contextsv_amd.host.CALL_DTYPE
+    def _snps(self, snps):
+        return (np.ascontiguousarray(snps["pos"], np.uint32), np.ascontiguousarray(snps["baf"], np.float64),
+                np.ascontiguousarray(snps["pfb"], np.float64), np.ascontiguousarray(snps["has_pfb"], np.uint8))
+
+    def query_snp_region(self, depth, start, end, mean_cov, sample_size, snps, cap=1 << 16):
+        depth = np.ascontiguousarray(depth, np.uint32)
+        pos, baf, pfb, has = self._snps(snps)
+        o_pos = np.zeros(cap, np.uint32); o_baf = np.zeros(cap); o_pfb = np.zeros(cap); o_l2 = np.zeros(cap); o_is = np.zeros(cap, np.uint8)
+        f = self.lib.orc_query_snp_region
+        f.restype = C.c_int64
+        f.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int, P, P, P, P, C.c_uint64, P, P, P, P, P, C.c_uint64]
+        k = f(_p(depth), len(depth), start, end, mean_cov, sample_size, _p(pos), _p(baf), _p(pfb), _p(has), len(pos),
+              _p(o_pos), _p(o_baf), _p(o_pfb), _p(o_l2), _p(o_is), cap)
+        return {"pos": o_pos[:k], "baf": o_baf[:k], "pfb": o_pfb[:k], "log2_cov": o_l2[:k], "is_snp": o_is[:k].astype(bool)}
+
+    def cn_prediction(self, depth, calls, hmm, mean_cov, snps, split, sample_size=20, min_cnv=2000):
+        depth = np.ascontiguousarray(depth, np.uint32)
+        pos, baf, pfb, has = self._snps(snps)
+        h = orc_hmm.from_buffer_copy(bytes(hmm))
+        cap = 2 * len(calls) + 16
+        buf = np.zeros(cap, calls.dtype)
+        buf[: len(calls)] = calls
+        if split:
+            f = self.lib.orc_split_cn_prediction
+            f.restype = C.c_int64
+            f.argtypes = [P, C.c_uint32, P, C.c_uint64, C.c_uint64, C.POINTER(orc_hmm), C.c_double, C.c_int, P, P, P, P, C.c_uint64]
+            n = f(_p(depth), len(depth), _p(buf), len(calls), cap, C.byref(h), mean_cov, sample_size, _p(pos), _p(baf), _p(pfb), _p(has), len(pos))
+            return buf[:n].copy()
+        f = self.lib.orc_cigar_cn_prediction
+        f.restype = None
+        f.argtypes = [P, C.c_uint32, P, C.c_uint64, C.POINTER(orc_hmm), C.c_double, C.c_int, C.c_uint32, P, P, P, P, C.c_uint64]
+        f(_p(depth), len(depth), _p(buf), len(calls), C.byref(h), mean_cov, sample_size, min_cnv, _p(pos), _p(baf), _p(pfb), _p(has), len(pos))
+        return buf[: len(calls)].copy()
+
     def merge_svs(self, calls, eps, min_pts, keep_noise, label_fn=None):
         """calls: CALL_DTYPE array. label_fn(start,end,eps,min_pts)->labels, default = oracle DBSCAN."""
         calls = np.ascontiguousarray(calls, CALL_DTYPE)
