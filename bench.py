@@ -97,8 +97,8 @@ def main():
             calls, tags, st, ms, tot = host.process_resident_pipelined(ctx, shard, n_steps, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
         if world > 1:
             # every step re-runs the same shard, so the job's call set is n_steps copies of `calls`
-            per_shard = {rank * 1000 + k: calls for k in range(min(n_steps, 32))}
-            parallel.gather_calls(per_shard, cap=GATHER_CAP * 32, dist=dist, device=dev)
+            per_shard = {rank * 1000 + k: calls[: GATHER_CAP // 8] for k in range(min(n_steps, 32))}
+            parallel.gather_calls(per_shard, cap=GATHER_CAP * 4, dist=dist, device=dev)     # fixed 1.5 MB buffer per rank
         return calls, st
 
     def barrier():
