@@ -11,6 +11,7 @@
 #include "log.h"
 #include "sv_caller.h"
 #include "sort_select.h"
+#include "split_caller.h"
 #include "synth.h"
 #include <algorithm>
 #include <vector>
@@ -199,6 +200,39 @@ int csvhost_process_resident_pipelined(csv_ctx *ctx, csv_shard *shard, uint64_t 
                 if (alt_tag) alt_tag[i] = c.alt_allele == "<DEL>" ? 0 : (c.alt_allele == "<INS>" ? 1 : 2);
             }
         }
+    })
+}
+
+// ---- split-read signatures (findSplitSVSignatures mirror) ---------------------------------------
+struct csvhost_split_call { uint32_t start, end; int32_t sv_type, cluster_size, aln_offset; uint32_t aln_flags; int32_t tid; };
+
+// records in file order; qname = "r<qname_id>". Output sorted by contig id, each contig's calls in the reference's order.
+int csvhost_split_signatures(csv_ctx *ctx, uint64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *flag, const uint8_t *mapq,
+                             const int32_t *ref_end, const int32_t *q_start, const int32_t *q_end, const uint32_t *qname_id, int n_targets,
+                             int min_mapq, csvhost_split_call *out, uint64_t cap, uint64_t *n_out)
+{
+    GUARD({
+        csvhost::set_context(ctx);
+        std::vector<SplitRecord> rec(n);
+        std::vector<std::string> qn(n), targets((size_t)n_targets);
+        for (int t = 0; t < n_targets; t++) targets[(size_t)t] = "contig" + std::to_string(t);
+        for (uint64_t i = 0; i < n; i++) {
+            rec[i] = SplitRecord{tid[i], pos[i], flag[i], mapq[i], ref_end[i], q_start[i], q_end[i]};
+            qn[i] = "r" + std::to_string(qname_id[i]);
+        }
+        SplitParams p; p.min_mapq = min_mapq;
+        std::unordered_map<std::string, std::vector<SVCall>> calls;
+        findSplitSVSignatures(rec, qn, targets, p, calls);
+        uint64_t k = 0;
+        for (int t = 0; t < n_targets; t++) {
+            auto it = calls.find(targets[(size_t)t]);
+            if (it == calls.end()) continue;
+            for (const SVCall &c : it->second) {
+                if (k < cap) out[k] = csvhost_split_call{c.start, c.end, (int32_t)c.sv_type, c.cluster_size, c.aln_offset, (uint32_t)c.aln_type.to_ulong(), t};
+                k++;
+            }
+        }
+        *n_out = k;
     })
 }
 

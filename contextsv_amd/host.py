@@ -52,6 +52,7 @@ def load() -> C.CDLL:
                                              _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_cn_prediction.argtypes = [_P, _P, C.c_int, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(_lib.csv_hmm),
                                           C.c_double, C.c_int, C.c_uint32, _P, _P, _P, _P, C.c_uint64]
+    lib.csvhost_split_signatures.argtypes = [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_read_chmm.argtypes = [C.c_char_p, C.POINTER(_lib.csv_hmm), C.POINTER(C.c_int32)]
     lib.csvhost_sort_select_check.argtypes = [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.csvhost_set_quiet(1)
@@ -205,6 +206,22 @@ def cn_prediction(ctx: Context, shard: Shard, calls: np.ndarray, hmm, mean_cov: 
     _check(load().csvhost_cn_prediction(ctx.h, shard.h, int(split), buf.ctypes.data, len(calls), cap, C.byref(n), C.byref(hmm), mean_cov,
                                         sample_size, min_cnv, pos.ctypes.data, baf.ctypes.data, pfb.ctypes.data, has.ctypes.data, len(pos)))
     return buf[: n.value].copy()
+
+
+SPLIT_CALL_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("sv_type", "<i4"), ("cluster_size", "<i4"), ("aln_offset", "<i4"),
+                             ("aln_flags", "<u4"), ("tid", "<i4")])
+
+
+def split_signatures(ctx: Context, tid, pos, flag, mapq, ref_end, q_start, q_end, qname_id, n_targets: int, min_mapq: int = 20) -> np.ndarray:
+    """findSplitSVSignatures mirror (qname of record i = "r<qname_id[i]>") -> calls sorted by contig id."""
+    a = [np.ascontiguousarray(x, dt) for x, dt in ((tid, np.int32), (pos, np.int32), (flag, np.uint16), (mapq, np.uint8), (ref_end, np.int32),
+                                                    (q_start, np.int32), (q_end, np.int32), (qname_id, np.uint32))]
+    n = len(a[0])
+    cap = 4 * n + 16
+    out = np.zeros(cap, SPLIT_CALL_DTYPE)
+    k = C.c_uint64(0)
+    _check(load().csvhost_split_signatures(ctx.h, n, *[x.ctypes.data for x in a], n_targets, min_mapq, out.ctypes.data, cap, C.byref(k)))
+    return out[: k.value].copy()
 
 
 def sort_select_check(keys: np.ndarray, nth: int):

@@ -142,6 +142,18 @@ class Oracle:
         f(_p(depth), len(depth), _p(buf), len(calls), C.byref(h), mean_cov, sample_size, min_cnv, _p(pos), _p(baf), _p(pfb), _p(has), len(pos))
         return buf[: len(calls)].copy()
 
+    def split_signatures(self, tid, pos, flag, mapq, ref_end, q_start, q_end, qname_id, min_mapq=20):
+        a = [np.ascontiguousarray(x, dt) for x, dt in ((tid, np.int32), (pos, np.int32), (flag, np.uint16), (mapq, np.uint8), (ref_end, np.int32),
+                                                        (q_start, np.int32), (q_end, np.int32), (qname_id, np.uint32))]
+        dt = np.dtype([("start", "<u4"), ("end", "<u4"), ("sv_type", "<i4"), ("cluster_size", "<i4"), ("aln_offset", "<i4"), ("aln_flags", "<u4"), ("tid", "<i4")])
+        n = len(a[0])
+        out = np.zeros(4 * n + 16, dt)
+        f = self.lib.orc_split_signatures
+        f.restype = C.c_int64
+        f.argtypes = [C.c_uint64, P, P, P, P, P, P, P, P, C.c_int, P, C.c_uint64]
+        k = f(n, *[_p(x) for x in a], min_mapq, _p(out), len(out))
+        return out[:k].copy()
+
     def merge_svs(self, calls, eps, min_pts, keep_noise, label_fn=None):
         """calls: CALL_DTYPE array. label_fn(start,end,eps,min_pts)->labels, default = oracle DBSCAN."""
         calls = np.ascontiguousarray(calls, CALL_DTYPE)
