@@ -707,6 +707,20 @@ void csvgpu_shard_free(csv_ctx *ctx, csv_shard *sh)
     shard_release(sh);
 }
 
+int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *sh, int32_t *ref_end, int32_t *q_start, int32_t *q_end)
+{
+    if (!ctx || !sh) return CSV_EINVAL;
+    const uint64_t n = sh->d.n_reads;
+    if (n == 0) return CSV_OK;
+    if (!ref_end || !q_start || !q_end) { ctx->err = "aln_intervals: null output"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    CSV_HIP(ctx, hipMemcpyAsync(ref_end, sh->ref_end, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipMemcpyAsync(q_start, sh->q_start, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipMemcpyAsync(q_end, sh->q_end, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
 int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *region_start, const uint32_t *region_end,
                                 const int32_t *sample_size, const uint64_t *win_off, uint64_t n_regions, double mean_cov,
                                 double *log2_cov, uint32_t *win_start, uint32_t *win_end)

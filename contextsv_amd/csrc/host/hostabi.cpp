@@ -293,6 +293,54 @@ int csvhost_cn_prediction(csv_ctx *ctx, csv_shard *shard, int split, csvhost_cal
     })
 }
 
+// ---- whole run (SVCaller::run mirror) over concatenated contig arrays -----------------------------
+// reads of contig t = [read_off[t], read_off[t+1]); cigar_off is global over the concatenated cigar array; SNPs of contig t =
+// [snp_off[t], snp_off[t+1]); qname of read i = "r<qname_id[i]>". Output: merged calls with contig id, contigs ascending.
+int csvhost_run(csv_ctx *ctx, int n_contigs, const uint64_t *read_off, const uint32_t *depth_len, const int32_t *pos, const uint16_t *flag,
+                const uint8_t *mapq, const uint64_t *cigar_off, const uint32_t *cigar, const uint32_t *qname_id,
+                const uint64_t *snp_off, const uint32_t *snp_pos, const double *snp_baf, const double *snp_pfb, const uint8_t *snp_has,
+                const csv_hmm *hmm, double eps, double min_pts_pct, int sample_size, uint32_t min_cnv,
+                csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out)
+{
+    GUARD({
+        std::vector<ChromosomeInput> contigs((size_t)n_contigs);
+        std::vector<std::vector<uint64_t>> local_off((size_t)n_contigs);
+        std::vector<std::vector<std::string>> qn((size_t)n_contigs);
+        std::vector<SNPTable> tabs((size_t)n_contigs);
+        for (int t = 0; t < n_contigs; t++) {
+            const uint64_t r0 = read_off[t], r1 = read_off[t + 1], n = r1 - r0;
+            local_off[t].resize(n + 1);
+            for (uint64_t i = 0; i <= n; i++) local_off[t][i] = cigar_off[r0 + i] - cigar_off[r0];
+            qn[t].resize(n);
+            for (uint64_t i = 0; i < n; i++) qn[t][i] = "r" + std::to_string(qname_id[r0 + i]);
+            tabs[t] = snp_table(snp_pos + snp_off[t], snp_baf + snp_off[t], snp_pfb + snp_off[t], snp_has + snp_off[t], snp_off[t + 1] - snp_off[t]);
+            ChromosomeInput &c = contigs[t];
+            c.name = "contig" + std::to_string(t);
+            c.reads.n_reads = n; c.reads.n_cigar = local_off[t][n];
+            c.reads.pos = pos + r0; c.reads.flag = flag + r0; c.reads.mapq = mapq + r0; c.reads.tid = nullptr;
+            c.reads.cigar_off = local_off[t].data(); c.reads.cigar = cigar + cigar_off[r0];
+            c.depth_len = depth_len[t]; c.qnames = &qn[t]; c.snps = &tabs[t];
+        }
+        RunParams P; P.dbscan_epsilon = eps; P.dbscan_min_pts_pct = min_pts_pct; P.sample_size = sample_size; P.min_cnv_length = min_cnv;
+        SVCaller caller(ctx);
+        std::unordered_map<std::string, std::vector<SVCall>> calls;
+        caller.run(contigs, chmm_from_pod(hmm), P, calls);
+        uint64_t k = 0;
+        for (int t = 0; t < n_contigs; t++) {
+            for (const SVCall &c : calls[contigs[t].name]) {
+                if (k < cap) {
+                    csvhost_call p;
+                    p.start = c.start; p.end = c.end; p.sv_type = (int32_t)c.sv_type; p.cluster_size = c.cluster_size; p.hmm_likelihood = c.hmm_likelihood;
+                    p.id = -1; p.aln_flags = (uint32_t)c.aln_type.to_ulong(); p.genotype = (int32_t)c.genotype; p.cn_state = c.cn_state; p.aln_offset = c.aln_offset;
+                    out[k] = p; out_tid[k] = t;
+                }
+                k++;
+            }
+        }
+        *n_out = k;
+    })
+}
+
 // ---- HMM file + Viterbi seam ------------------------------------------------------------------
 int csvhost_read_chmm(const char *path, csv_hmm *out, int32_t *N)
 {

@@ -8,6 +8,7 @@
 #include <thread>
 #include <stdexcept>
 
+#include "dbscan.h"
 #include "log.h"
 #include "sort_select.h"
 
@@ -181,4 +182,84 @@ void SVCaller::processChromosome(const std::string &chr, const csv_reads &reads,
         throw;
     }
     if (keep_shard) *keep_shard = sh; else csvgpu_shard_free(ctx, sh);
+}
+
+
+namespace {
+struct EmptySnps : SNPSource {
+    void query(uint32_t, uint32_t, std::vector<uint32_t> &, std::unordered_map<uint32_t, double> &, std::unordered_map<uint32_t, double> &) const override {}
+};
+}  // namespace
+
+void SVCaller::run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm, const RunParams &P,
+                   std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls)
+{
+    csvhost::set_context(ctx);
+    const EmptySnps no_snps;
+    std::vector<csv_shard *> shards(contigs.size(), nullptr);
+    std::vector<ChrStats> stats(contigs.size());
+    std::unordered_map<std::string, size_t> index_of;
+    auto free_all = [&] { for (csv_shard *s : shards) if (s) csvgpu_shard_free(ctx, s); };
+    try {
+        // depth pass + CIGAR pass + CIGAR merge (sv_caller.cpp:794-863); the reference pre-seeds the map with every contig
+        for (size_t i = 0; i < contigs.size(); i++) {
+            const ChromosomeInput &c = contigs[i];
+            index_of[c.name] = i;
+            std::vector<SVCall> calls;
+            if (P.cigar_svs) processChromosome(c.name, c.reads, c.seq, c.depth_len, P.dbscan_epsilon, P.dbscan_min_pts_pct, calls, stats[i], &shards[i]);
+            whole_genome_sv_calls[c.name] = std::move(calls);
+        }
+        CNVCaller cnv(ctx);
+        cnv.sample_size = P.sample_size; cnv.min_cnv_length = P.min_cnv_length;
+        if (P.cigar_svs && P.cigar_cn) {                                               // :865-881
+            printMessage("Running copy number predictions on CIGAR SVs...");
+            for (auto &entry : whole_genome_sv_calls) {
+                if (entry.second.empty()) continue;
+                const size_t i = index_of.at(entry.first);
+                cnv.runCIGARCopyNumberPrediction(entry.first, entry.second, hmm, stats[i].mean_chr_cov, shards[i],
+                                                 contigs[i].snps ? *contigs[i].snps : (const SNPSource &)no_snps);
+            }
+        }
+        if (P.split_svs) {                                                             // :885-917
+            std::vector<SplitRecord> records;
+            std::vector<std::string> qnames, targets;
+            for (size_t i = 0; i < contigs.size(); i++) {
+                const ChromosomeInput &c = contigs[i];
+                targets.push_back(c.name);
+                if (!c.qnames || !shards[i]) continue;
+                const uint64_t n = c.reads.n_reads;
+                std::vector<int32_t> ref_end(n), q_start(n), q_end(n);
+                check(ctx, csvgpu_aln_intervals_resident(ctx, shards[i], ref_end.data(), q_start.data(), q_end.data()), "alignment intervals");
+                for (uint64_t r = 0; r < n; r++) {
+                    records.push_back(SplitRecord{(int32_t)i, c.reads.pos[r], c.reads.flag[r], c.reads.mapq[r], ref_end[r], q_start[r], q_end[r]});
+                    qnames.push_back((*c.qnames)[r]);
+                }
+            }
+            std::unordered_map<std::string, std::vector<SVCall>> split_calls;
+            SplitParams sp; sp.min_mapq = min_mapq;
+            findSplitSVSignatures(records, qnames, targets, sp, split_calls);
+            for (auto &entry : split_calls) {
+                if (entry.second.empty()) continue;
+                const size_t i = index_of.at(entry.first);
+                cnv.runSplitReadCopyNumberPredictions(entry.first, entry.second, hmm, stats[i].mean_chr_cov, shards[i],
+                                                      contigs[i].snps ? *contigs[i].snps : (const SNPSource &)no_snps);
+            }
+            if (P.merge_split_svs) for (auto &entry : split_calls) mergeSVs(entry.second, 0.1, 2, true);
+            for (auto &entry : split_calls) {
+                std::vector<SVCall> &dst = whole_genome_sv_calls[entry.first];
+                dst.insert(dst.end(), entry.second.begin(), entry.second.end());
+            }
+        }
+        if (P.merge_final_svs) for (auto &entry : whole_genome_sv_calls) mergeSVs(entry.second, 0.1, 2, true);   // :919-927
+        uint32_t total = 0;
+        for (const auto &entry : whole_genome_sv_calls) {
+            total += getSVCount(entry.second);
+            printMessage("Total SVs detected for " + entry.first + ": " + std::to_string(getSVCount(entry.second)));
+        }
+        printMessage("Total SVs detected: " + std::to_string(total));
+    } catch (...) {
+        free_all();
+        throw;
+    }
+    free_all();
 }

@@ -9,6 +9,11 @@
 #include <vector>
 
 #include "../../../include/csvgpu.h"
+#include <unordered_map>
+
+#include "cnv_caller.h"
+#include "khmm.h"
+#include "split_caller.h"
 #include "sv_object.h"
 
 // 4-bit packed read sequences (BAM encoding, two bases per byte, high nibble first); optional.
@@ -24,6 +29,24 @@ struct ChrStats {
     double mean_chr_cov = 0.0;
     int dbscan_min_pts = 0;
     double ms_device = 0.0, ms_host_merge = 0.0;
+};
+
+// One contig of a run: decoded records (+ optional sequences and query names for the split-read pass) and its SNPs.
+struct ChromosomeInput {
+    std::string name;
+    csv_reads reads{};                      // host arrays, file order
+    const SeqStore *seq = nullptr;
+    uint32_t depth_len = 0;                 // contig length + 1
+    const std::vector<std::string> *qnames = nullptr;   // [n_reads]; nullptr: this contig takes no part in the split-read pass
+    const SNPSource *snps = nullptr;        // nullptr: no SNPs (every window gets the dummy observation)
+};
+
+struct RunParams {
+    double dbscan_epsilon = 0.1;            // --eps          (input_data.cpp:18-37)
+    double dbscan_min_pts_pct = 0.1;        // --min-pts-pct
+    int sample_size = 20;                   // --sample-size
+    uint32_t min_cnv_length = 2000;         // --min-cnv
+    bool cigar_svs = true, cigar_cn = true, split_svs = true, merge_split_svs = true, merge_final_svs = true;   // sv_caller.cpp:749-753
 };
 
 class SVCaller {
@@ -51,6 +74,13 @@ public:
     void processResidentChromosomesPipelined(const std::vector<csv_shard *> &shards, const SeqStore *seq, double dbscan_epsilon,
                                              double dbscan_min_pts_pct, std::vector<std::vector<SVCall>> &calls,
                                              std::vector<ChrStats> &stats);
+
+    // Pass ordering of SVCaller::run (sv_caller.cpp:747-946) over in-memory contigs: depth + CIGAR pass + CIGAR merge per
+    // contig -> CIGAR copy-number predictions -> split-read signatures -> their copy-number predictions ->
+    // mergeSVs(0.1, 2, keep_noise) on the split calls -> concatenation -> final mergeSVs(0.1, 2, keep_noise).
+    // Every contig's shard (reads, depth map) stays resident in HBM until the run ends. VCF output is not part of this path.
+    void run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm, const RunParams &params,
+             std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls);
 
     // signature -> SVCall with the reference's field values (sv_caller.cpp:569-643)
     static SVCall toSVCall(const csv_sig &s, const SeqStore *seq);

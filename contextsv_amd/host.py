@@ -53,6 +53,8 @@ def load() -> C.CDLL:
     lib.csvhost_cn_prediction.argtypes = [_P, _P, C.c_int, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(_lib.csv_hmm),
                                           C.c_double, C.c_int, C.c_uint32, _P, _P, _P, _P, C.c_uint64]
     lib.csvhost_split_signatures.argtypes = [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.csvhost_run.argtypes = [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_lib.csv_hmm), C.c_double, C.c_double,
+                                C.c_int, C.c_uint32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_read_chmm.argtypes = [C.c_char_p, C.POINTER(_lib.csv_hmm), C.POINTER(C.c_int32)]
     lib.csvhost_sort_select_check.argtypes = [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.csvhost_set_quiet(1)
@@ -222,6 +224,36 @@ def split_signatures(ctx: Context, tid, pos, flag, mapq, ref_end, q_start, q_end
     k = C.c_uint64(0)
     _check(load().csvhost_split_signatures(ctx.h, n, *[x.ctypes.data for x in a], n_targets, min_mapq, out.ctypes.data, cap, C.byref(k)))
     return out[: k.value].copy()
+
+
+def run(ctx: Context, contigs: list, hmm, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000):
+    """SVCaller::run mirror. contigs: list of dicts {reads: Reads, depth_len, qname_id: uint32[n], snps: dict}.
+    -> (merged calls, contig id per call)."""
+    read_off = np.zeros(len(contigs) + 1, np.uint64)
+    read_off[1:] = np.cumsum([c["reads"].n_reads for c in contigs])
+    cig_base = np.concatenate([[0], np.cumsum([c["reads"].n_cigar for c in contigs])]).astype(np.uint64)
+    pos = np.ascontiguousarray(np.concatenate([c["reads"].pos for c in contigs]), np.int32)
+    flag = np.ascontiguousarray(np.concatenate([c["reads"].flag for c in contigs]), np.uint16)
+    mapq = np.ascontiguousarray(np.concatenate([c["reads"].mapq for c in contigs]), np.uint8)
+    cigar = np.ascontiguousarray(np.concatenate([c["reads"].cigar for c in contigs]), np.uint32)
+    coff = np.ascontiguousarray(np.concatenate([c["reads"].cigar_off[:-1] + cig_base[i] for i, c in enumerate(contigs)] + [cig_base[-1:]]), np.uint64)
+    qid = np.ascontiguousarray(np.concatenate([c["qname_id"] for c in contigs]), np.uint32)
+    dl = np.asarray([c["depth_len"] for c in contigs], np.uint32)
+    snp_off = np.zeros(len(contigs) + 1, np.uint64)
+    snp_off[1:] = np.cumsum([len(c["snps"]["pos"]) for c in contigs])
+    sp = np.ascontiguousarray(np.concatenate([c["snps"]["pos"] for c in contigs]), np.uint32)
+    sb = np.ascontiguousarray(np.concatenate([c["snps"]["baf"] for c in contigs]), np.float64)
+    sf = np.ascontiguousarray(np.concatenate([c["snps"]["pfb"] for c in contigs]), np.float64)
+    sh = np.ascontiguousarray(np.concatenate([c["snps"]["has_pfb"] for c in contigs]), np.uint8)
+    cap = len(cigar) + 1024
+    out = np.zeros(cap, CALL_DTYPE)
+    tid = np.zeros(cap, np.int32)
+    n = C.c_uint64(0)
+    _check(load().csvhost_run(ctx.h, len(contigs), read_off.ctypes.data, dl.ctypes.data, pos.ctypes.data, flag.ctypes.data, mapq.ctypes.data,
+                              coff.ctypes.data, cigar.ctypes.data, qid.ctypes.data, snp_off.ctypes.data, sp.ctypes.data, sb.ctypes.data,
+                              sf.ctypes.data, sh.ctypes.data, C.byref(hmm), eps, min_pts_pct, sample_size, min_cnv, out.ctypes.data,
+                              tid.ctypes.data, cap, C.byref(n)))
+    return out[: n.value].copy(), tid[: n.value].copy()
 
 
 def sort_select_check(keys: np.ndarray, nth: int):

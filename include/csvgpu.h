@@ -227,6 +227,9 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, 
  * label_ins) of the last csvgpu_chr_pipeline_dev() on `shard` to host memory with one synchronisation. */
 int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *shard, const csv_chr_result *result, csv_sig *host_sig, int32_t *host_labels);
 
+/* The alignment intervals that the last csvgpu_chr_pipeline_dev() computed for every record of `shard`, copied to host. */
+int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *shard, int32_t *ref_end, int32_t *q_start, int32_t *q_end);
+
 /* csvgpu_window_log2 on the depth map that the last csvgpu_chr_pipeline_dev() left resident in `shard`
  * (region tables and outputs are host memory; the depth map never leaves HBM). */
 int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *region_start, const uint32_t *region_end,

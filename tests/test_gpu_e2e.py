@@ -1,0 +1,148 @@
+"""End to end over the whole hot path (SVCaller::run pass ordering, sv_caller.cpp:747-946) on three synthetic contigs:
+CIGAR scan + depth + ordering + DBSCAN + mergeSVs -> CIGAR copy-number predictions -> split-read signatures -> their
+copy-number predictions -> mergeSVs(0.1, 2, keep_noise) -> concatenation -> final mergeSVs — product (GPU kernels + C++ host
+mirror) against the same chain composed from the oracle's pieces in Python."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from contextsv_amd import Reads, host, make_hmm
+from hmm_params import WGS_HMM
+from test_gpu_split import _make_split_shard
+
+pytestmark = pytest.mark.gpu
+M, I, D, N, S, H = 0, 1, 2, 3, 4, 5
+CONTIG_LEN = 3_000_000
+
+
+def _cigar_reads(rng, tid, qid0):
+    """~12x of 8 kb reads over the first 1.2 Mb with small indels, clips and shared SV events (some >= 2 kb for the CNV pass)."""
+    events = []
+    for _ in range(14):
+        events.append((int(rng.integers(20_000, 1_150_000)), rng.choice(["D", "I"]), int(rng.choice([60, 150, 400, 2500, 6000])), bool(rng.random() < 0.4)))
+    events.sort()
+    recs = []
+    n = int(12 * 1_200_000 / 8000)
+    for r in range(n):
+        p = int(rng.integers(0, 1_190_000))
+        ln = int(rng.integers(5000, 11000))
+        hap = int(rng.integers(0, 2))
+        ops, ref, end = [], p, p + ln
+        if rng.random() < 0.3:
+            ops.append((S, int(rng.integers(10, 300))))
+        evs = [e for e in events if p + 200 < e[0] < end - 200 and (e[3] or hap == 0)]
+        cur = ref
+        for (loc, kind, size, _hom) in evs:
+            loc += int(rng.integers(-4, 5))
+            if loc <= cur + 10:
+                continue
+            # small indels inside the match run
+            while cur + 400 < loc:
+                step = int(rng.integers(100, 400))
+                ops.append((M, step)); cur += step
+                if rng.random() < 0.5:
+                    ops.append((I, int(rng.integers(1, 4))))
+                else:
+                    d = int(rng.integers(1, 4)); ops.append((D, d)); cur += d
+            ops.append((M, loc - cur)); cur = loc
+            sz = max(50, int(size * (1 + rng.uniform(-0.02, 0.02))))
+            if kind == "D":
+                ops.append((D, sz)); cur += sz
+            else:
+                ops.append((I, sz))
+        if end > cur:
+            ops.append((M, end - cur))
+        if rng.random() < 0.3:
+            ops.append((S, int(rng.integers(10, 300))))
+        fl = 0x10 if rng.random() < 0.5 else 0
+        recs.append((tid, p, fl, 60 if rng.random() > 0.05 else 7, ops, qid0 + r))
+    return recs, qid0 + n
+
+
+def _build(seed):
+    rng = np.random.default_rng(seed)
+    reads_s, tid_s, qn_s, n_contigs = _make_split_shard(seed, n_events=40)
+    # unpack the split shard back into record tuples
+    recs = []
+    for i in range(reads_s.n_reads):
+        a, b = int(reads_s.cigar_off[i]), int(reads_s.cigar_off[i + 1])
+        ops = [(int(w & 15), int(w >> 4)) for w in reads_s.cigar[a:b]]
+        recs.append((int(tid_s[i]), int(reads_s.pos[i]), int(reads_s.flag[i]), int(reads_s.mapq[i]), ops, int(qn_s[i])))
+    qid = int(qn_s.max()) + 1
+    for t in range(n_contigs):
+        extra, qid = _cigar_reads(rng, t, qid)
+        recs += extra
+    recs.sort(key=lambda r: (r[0], r[1]))
+    contigs = []
+    for t in range(n_contigs):
+        rt = [r for r in recs if r[0] == t]
+        reads = Reads.from_cigar_lists([r[1] for r in rt], [r[2] for r in rt], [r[3] for r in rt], [r[4] for r in rt])
+        n_snp = 900
+        pos = np.sort(rng.choice(np.arange(1000, 1_250_000), n_snp, replace=False)).astype(np.uint32)
+        snps = {"pos": pos, "baf": np.clip(np.where(rng.random(n_snp) < 0.6, 0.5 + rng.normal(0, 0.05, n_snp), rng.choice([0.0, 1.0], n_snp)), 0, 1),
+                "pfb": rng.uniform(0.05, 0.95, n_snp), "has_pfb": (rng.random(n_snp) < 0.2).astype(np.uint8)}
+        contigs.append({"reads": reads, "depth_len": CONTIG_LEN + 1, "qname_id": np.array([r[5] for r in rt], np.uint32), "snps": snps})
+    return contigs
+
+
+def _full(start, end, sv_type, cluster, flags, aln_offset=None):
+    c = host.make_calls(start, end, sv_type, cluster)
+    c["aln_flags"] = flags
+    if aln_offset is not None:
+        c["aln_offset"] = aln_offset
+    return c
+
+
+def _orc_merge(oracle, full, eps, min_pts, keep_noise):
+    small = np.zeros(len(full), oracle_lib.CALL_DTYPE)
+    for f in ("start", "end", "sv_type", "cluster_size", "hmm_likelihood"):
+        small[f] = full[f]
+    small["id"] = np.arange(len(full))
+    m = oracle.merge_svs(small, eps, min_pts, keep_noise)
+    out = full[m["id"]].copy()
+    out["cluster_size"] = m["cluster_size"]
+    return out
+
+
+def test_whole_path_end_to_end(ctx, oracle):
+    contigs = _build(7)
+    hmm = make_hmm(**WGS_HMM)
+    got, got_tid = host.run(ctx, contigs, hmm, eps=0.1, min_pts_pct=0.1)
+
+    # ---- the same chain from the oracle's pieces --------------------------------------------------
+    cigar_calls, depths, means = [], [], []
+    for c in contigs:
+        r = c["reads"]
+        sig = oracle.cigar_scan(r, c["depth_len"])
+        depth, s, nz = oracle.depth(r, c["depth_len"])
+        mean = s / nz
+        min_pts = int(np.ceil(mean * 0.1))
+        kind = sig["qpos_kind"] & 3
+        full = _full(sig["start"], sig["end"], np.where(kind == 1, 0, 3), 0, np.where(kind == 0, 1, np.where(kind == 1, 2, 4)))
+        full = _orc_merge(oracle, full, 0.1, min_pts, False)
+        full = oracle.cn_prediction(depth, full, hmm, mean, c["snps"], split=False)
+        cigar_calls.append(full); depths.append(depth); means.append(mean)
+    tid = np.concatenate([np.full(c["reads"].n_reads, t, np.int32) for t, c in enumerate(contigs)])
+    cat = lambda f: np.concatenate([getattr(c["reads"], f) for c in contigs])
+    iv = [oracle.aln_intervals(c["reads"]) for c in contigs]
+    sp = oracle.split_signatures(tid, cat("pos"), cat("flag"), cat("mapq"), np.concatenate([x[0] for x in iv]), np.concatenate([x[1] for x in iv]),
+                                 np.concatenate([x[2] for x in iv]), np.concatenate([c["qname_id"] for c in contigs]))
+    exp, exp_tid = [], []
+    for t, c in enumerate(contigs):
+        st = sp[sp["tid"] == t]
+        split_full = _full(st["start"], st["end"], st["sv_type"], st["cluster_size"], st["aln_flags"], st["aln_offset"])
+        if len(split_full):
+            split_full = oracle.cn_prediction(depths[t], split_full, hmm, means[t], c["snps"], split=True)
+            split_full = _orc_merge(oracle, split_full, 0.1, 2, True)
+        whole = np.concatenate([cigar_calls[t], split_full])
+        whole = _orc_merge(oracle, whole, 0.1, 2, True)
+        exp.append(whole); exp_tid.append(np.full(len(whole), t, np.int32))
+    exp, exp_tid = np.concatenate(exp), np.concatenate(exp_tid)
+
+    assert len(got) == len(exp) and len(got) > 20
+    assert np.array_equal(got_tid, exp_tid)
+    for f in ("start", "end", "sv_type", "cluster_size", "aln_flags", "genotype", "cn_state", "aln_offset"):
+        assert np.array_equal(got[f], exp[f]), f
+    np.testing.assert_allclose(got["hmm_likelihood"], exp["hmm_likelihood"], rtol=0, atol=1e-6)
+    assert (got["cn_state"] != 0).any() and (got["aln_flags"] & (1 << 8)).any()       # the HMM did update calls
+    assert ((got["aln_flags"] & (1 << 3)) != 0).any() or ((got["aln_flags"] & (1 << 4)) != 0).any()   # split evidence survived the merges
