@@ -76,8 +76,8 @@ struct ScanCounters {
     unsigned long long n_del;        // kind == DEL
     unsigned long long depth_sum;
     unsigned int       depth_nonzero;
-    unsigned int       max_start;
-    unsigned int       max_len;      // max (end - start) over emitted signatures
+    unsigned int       max_start;    // 0xffffffff if a signature start exceeded scan_start_limit(depth_len), else 0
+    unsigned int       max_len;      // unused
     unsigned int       unsorted;     // != 0 if pos[] is not non-decreasing
     int                min_pts;      // written by the min_pts kernel
     int                pad;
@@ -115,6 +115,7 @@ static inline int bits_of(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } r
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
                        int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt);
+uint32_t scan_start_limit(uint32_t depth_len);   // exclusive bound on signature starts that the ordering keys are sized for
 // depth.hip
 void launch_prefix_max(hipStream_t s, const int32_t *in, int32_t *out, uint64_t n, void *tmp /* >= 4 KiB + n/1024*4 */);
 size_t prefix_max_tmp_bytes(uint64_t n);

@@ -166,13 +166,13 @@ static bool sortws_carve(Arena &a, uint64_t n, SortWs &w)
 
 // sig_raw[0..n) (arbitrary order) -> sig_sorted in the reference's vector order; optional SoA start/end.
 // with_type: DEL calls first, then INS calls (per-type subsequences of the vector).
-static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, uint32_t max_start, uint32_t max_len,
+static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, uint32_t depth_len, uint32_t overflow,
                              bool with_type, SortWs &w, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out)
 {
     if (!n) return;
     TimerScope ts(ctx, CSV_K_SORT);
-    (void)max_len;
-    const int start_bits = std::max(1, bits_of(max_start));
+    // starts are < scan_start_limit(depth_len) unless the scan flagged an overflow (then the full 32 bits are sorted)
+    const int start_bits = overflow ? 32 : std::max(1, bits_of((uint64_t)scan_start_limit(depth_len) - 1));
     const int type_pos = with_type ? start_bits : -1;
     const int key_bits = start_bits + (with_type ? 1 : 0);
     launch_sig_make_keys(ctx->stream, sig_raw, n, 0, type_pos, w.k0, w.v0);
@@ -361,7 +361,7 @@ int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, 
     SortWs w;
     csv_sig *sig_sorted = (csv_sig *)arena_alloc(ctx->work, n * sizeof(csv_sig));
     if (!sortws_carve(ctx->work, n, w) || !sig_sorted) { ctx->err = "arena exhausted (sort)"; return CSV_ENOMEM; }
-    order_signatures(ctx, sig_raw, n, h.max_start, h.max_len, false, w, sig_sorted, nullptr, nullptr);
+    order_signatures(ctx, sig_raw, n, depth_len, h.max_start, false, w, sig_sorted, nullptr, nullptr);
     CSV_HIP(ctx, hipMemcpyAsync(out, sig_sorted, n * sizeof(csv_sig), hipMemcpyDeviceToHost, ctx->stream));
     CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CSV_OK;
@@ -832,7 +832,7 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
     launch_min_pts(s, cnt, min_pts_pct);
 
     // ordering: DEL calls then INS calls, each in chr_sv_calls order
-    order_signatures(ctx, sh->sig_raw, n, h.max_start, h.max_len, true, w, sig_sorted, st, en);
+    order_signatures(ctx, sh->sig_raw, n, sh->depth_len, h.max_start, true, w, sig_sorted, st, en);
 
     // per-type interval DBSCAN (mergeSVs walks DEL ... INS, sv_object.cpp:62-68)
     {

@@ -21,6 +21,7 @@ namespace csv {
 
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
+constexpr uint32_t CAND_OPS = (1u << OP_I) | (1u << OP_D) | (1u << OP_S);
 constexpr uint32_t SIG_BUF = 1024;           // signatures staged per workgroup (16 KiB LDS)
 
 struct Chunk {
@@ -61,6 +62,13 @@ __device__ __forceinline__ uint64_t wave_lower_bound(const uint64_t *__restrict_
     return lo;
 }
 
+// lane `i` (wave-uniform) of a per-lane value, as a scalar
+__device__ __forceinline__ uint32_t bcast32(uint32_t v, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i); }
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t i)
+{
+    return ((uint64_t)bcast32((uint32_t)(v >> 32), i) << 32) | bcast32((uint32_t)v, i);
+}
+
 struct ScanMd {
     uint64_t c0, c1;
     uint32_t p0, fl, mq, unsorted;
@@ -82,20 +90,20 @@ __device__ __forceinline__ ScanMd scan_load_md(uint64_t r, uint64_t n_reads, con
 __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint8_t *__restrict__ mapq, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
-    int vec_ok, uint32_t depth_len, uint32_t min_oplen, uint32_t min_mapq, int emit,
+    int vec_ok, uint32_t depth_len, uint32_t start_limit, uint32_t min_oplen, uint32_t min_mapq, int emit,
     csv_sig *__restrict__ sig_out, uint64_t sig_cap, int32_t *__restrict__ ref_end, int32_t *__restrict__ q_start,
     int32_t *__restrict__ q_end, uint32_t *__restrict__ ckpt, ScanCounters *__restrict__ cnt)
 {
     __shared__ csv_sig buf[SIG_BUF];
-    __shared__ uint32_t buf_n, blk_max_start, blk_max_len, blk_n_del;
+    __shared__ uint32_t buf_n, blk_n_del, blk_direct, blk_overflow;
     __shared__ unsigned long long blk_gbase;
 
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { buf_n = 0; blk_max_start = 0; blk_max_len = 0; blk_n_del = 0; }
-    __syncthreads();
+    if (threadIdx.x == 0) { buf_n = 0; blk_n_del = 0; blk_direct = 0; blk_overflow = 0; }
+    // (the __syncthreads() after the split-point search below also publishes these)
 
-    uint32_t my_max_start = 0, my_max_len = 0, my_n_del = 0;
+    uint32_t my_n_del = 0, my_overflow = 0;
 
     // Work split: read lengths are log-normal, so handing out reads round-robin leaves the slowest wave with ~1.5x the
     // mean work (measured: waves alive 65 % of the kernel). Instead every wave takes the CONTIGUOUS run of reads whose
@@ -105,24 +113,48 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
     const uint64_t n_waves = (uint64_t)gridDim.x * SCAN_WAVES;
     const uint64_t wave_gid = (uint64_t)blockIdx.x * SCAN_WAVES + wave;
     const uint64_t share = (n_cigar + n_waves - 1) / n_waves;
-    const uint64_t r_begin = wave_lower_bound(cigar_off, n_reads, wave_gid * share, lane);
-    const uint64_t r_end = (wave_gid + 1 == n_waves) ? n_reads : wave_lower_bound(cigar_off, n_reads, (wave_gid + 1) * share, lane);
+    // one search per wave (its own start); the end is the next wave's start, handed over through LDS
+    __shared__ uint64_t split_s[SCAN_WAVES + 1];
+    {
+        const uint64_t b = wave_lower_bound(cigar_off, n_reads, wave_gid * share, lane);
+        if (lane == 0) split_s[wave] = b;
+        if (wave == SCAN_WAVES - 1) {
+            const uint64_t e = (wave_gid + 1 >= n_waves) ? n_reads : wave_lower_bound(cigar_off, n_reads, (wave_gid + 1) * share, lane);
+            if (lane == 0) split_s[SCAN_WAVES] = e;
+        }
+    }
+    __syncthreads();
+    const uint64_t r_begin = split_s[wave];
+    const uint64_t r_end = split_s[wave + 1];
 
-    // Software pipeline across reads: while read r is walked, the metadata of the wave's next read is already in
-    // flight, and its first chunk is requested when the current read reaches its last chunk.
-    ScanMd md = scan_load_md(r_begin < r_end ? r_begin : n_reads, n_reads, pos, flag, mapq, cigar_off);
-    Chunk first = load_chunk(cigar, (md.c0 & ~255ull) + (uint64_t)lane * 4, n_cigar, vec_ok);
-    for (uint64_t r = r_begin; r < r_end; r++) {
-        const ScanMd cm = md;
-        const uint64_t c0 = cm.c0, c1 = cm.c1;
-        const uint32_t p0 = cm.p0;
-        const uint32_t fl = cm.fl;
-        const bool have_next = r + 1 < r_end;
-        if (have_next) md = scan_load_md(r + 1, n_reads, pos, flag, mapq, cigar_off);
+    // Per-read metadata is loaded for 64 reads at a time, lane-parallel and coalesced (lane l <-> read rb + l), and handed to
+    // the wave with readlane; a wave's whole share is usually one batch. Inside the read loop only CIGAR chunk loads remain:
+    // the next read's first chunk is requested when the current read reaches its last chunk.
+    for (uint64_t rb = r_begin; rb < r_end; rb += WAVE) {
+    const uint64_t nb_reads = min((uint64_t)WAVE, r_end - rb);
+    uint64_t l_c0 = 0; uint32_t l_p0 = 0, l_flmq = 0, l_uns = 0;     // lane l: first CIGAR word, pos, flag | mapq << 16 of read rb + l
+    if ((uint64_t)lane < nb_reads) {
+        const uint64_t rr = rb + lane;
+        l_c0 = cigar_off[rr];
+        const int32_t p = pos[rr];
+        l_p0 = (uint32_t)p; l_flmq = (uint32_t)flag[rr] | ((uint32_t)mapq[rr] << 16);
+        l_uns = (rr > 0 && p < pos[rr - 1]) ? 1u : 0u;
+    }
+    const uint64_t batch_end_word = cigar_off[rb + nb_reads];        // wave-uniform
+    if (__ballot(l_uns != 0) && lane == 0) cnt->unsorted = 1u;
+    Chunk first = load_chunk(cigar, (bcast64(l_c0, 0) & ~255ull) + (uint64_t)lane * 4, n_cigar, vec_ok);
+    for (uint32_t ri = 0; ri < (uint32_t)nb_reads; ri++) {
+        const uint64_t r = rb + ri;
+        const bool have_next = ri + 1 < (uint32_t)nb_reads;
+        const uint64_t c0 = bcast64(l_c0, ri);
+        const uint64_t c1 = have_next ? bcast64(l_c0, ri + 1) : batch_end_word;     // cigar_off[r + 1]
+        const uint32_t p0 = bcast32(l_p0, ri);
+        const uint32_t flmq = bcast32(l_flmq, ri);
+        const uint32_t fl = flmq & 0xffffu, mq = flmq >> 16;
+        const uint64_t next_base = c1 & ~255ull;
         bool next_first_issued = false;
         // sv_caller.cpp:526
-        const bool emit_ok = emit && !(fl & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && cm.mq >= min_mapq;
-        if (lane == 0 && cm.unsorted) cnt->unsorted = 1u;
+        const bool emit_ok = emit && !(fl & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && mq >= min_mapq;
 
         // The kernel is VALU-issue-bound, so the common chunk does the minimum: decode, ONE DPP scan (reference
         // cursor: needed for the checkpoint and ref_end), lane-local query sums. Query cursors, skipped-clip
@@ -143,7 +175,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
             const bool more = chunk + 4 * WAVE < c1;
             if (more) nxt = load_chunk(cigar, chunk + 4 * WAVE + (uint64_t)lane * 4, n_cigar, vec_ok);   // prefetch next 1 KiB
             else if (have_next) {                                                                        // last chunk: next read's first
-                first = load_chunk(cigar, (md.c0 & ~255ull) + (uint64_t)lane * 4, n_cigar, vec_ok);
+                first = load_chunk(cigar, next_base + (uint64_t)lane * 4, n_cigar, vec_ok);
                 next_first_issued = true;
             }
 
@@ -158,7 +190,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
                 ql[k] = ((QRY_OPS >> op[k]) & 1u) ? len[k] : 0u;
                 lane_ref += rl[k];
                 lane_q += ql[k];
-                big |= (len[k] >= min_oplen) ? 1u : 0u;
+                big |= (((CAND_OPS >> op[k]) & 1u) && len[k] >= min_oplen) ? 1u : 0u;   // only I / D / S ops can become signatures
                 qst |= (QST_OPS >> op[k]) & 1u;
             }
             const uint32_t incl_ref = wave_incl_sum_dpp(lane_ref);
@@ -240,11 +272,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
                                     if (lane == 0) g = atomicAdd(&cnt->n_sig, (unsigned long long)n_e);
                                     g = __shfl(g, 0, 64);
                                     if (e && g + rank < sig_cap) sig_out[g + rank] = sg;
+                                    if (lane == 0) atomicAdd(&blk_direct, 1u);
                                 }
                                 if (e) {
-                                    my_max_start = max(my_max_start, sg.start);
-                                    my_max_len = max(my_max_len, sg.end - sg.start);
                                     my_n_del += (kind == CSV_KIND_DEL);
+                                    my_overflow |= (sg.start >= start_limit);      // start does not fit the sort key (never for sane input)
                                 }
                             }
                             if ((skipped >> k) & 1u) skk += len[k];
@@ -258,7 +290,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
             ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)incl_ref, 63);
             if (more) cur = nxt;
         }
-        if (have_next && !next_first_issued) first = load_chunk(cigar, (md.c0 & ~255ull) + (uint64_t)lane * 4, n_cigar, vec_ok);
+        if (have_next && !next_first_issued) first = load_chunk(cigar, next_base + (uint64_t)lane * 4, n_cigar, vec_ok);
 
         const uint32_t q_total = wave_total_dpp(acc_q);
         if (lane == 0) {
@@ -270,29 +302,38 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
             q_end[r] = (int32_t)q_total;
         }
     }
+    }
+
 
     if (!emit) return;
-    // workgroup epilogue: fold maxima, flush the LDS buffer with one global atomic
-    my_max_start = wave_max(my_max_start);
-    my_max_len = wave_max(my_max_len);
+    // workgroup epilogue: ONE global atomic per workgroup reserves the output range of the LDS buffer (the DEL count rides
+    // in a second word only when non-zero). Every extra same-line atomic per workgroup costs tens of microseconds chip-wide.
     my_n_del = wave_sum(my_n_del);
+    const bool wave_overflow = __ballot(my_overflow != 0) != 0;
     if (lane == 0) {
-        if (my_max_start) atomicMax(&blk_max_start, my_max_start);
-        if (my_max_len) atomicMax(&blk_max_len, my_max_len);
         if (my_n_del) atomicAdd(&blk_n_del, my_n_del);
+        if (wave_overflow) atomicOr(&blk_overflow, 1u);
     }
     __syncthreads();
     const uint32_t nb = buf_n;
     if (threadIdx.x == 0) {
         blk_gbase = nb ? atomicAdd(&cnt->n_sig, (unsigned long long)nb) : 0ull;
-        if (blk_max_start) atomicMax(&cnt->max_start, blk_max_start);
-        if (blk_max_len) atomicMax(&cnt->max_len, blk_max_len);
         if (blk_n_del) atomicAdd(&cnt->n_del, (unsigned long long)blk_n_del);
+        if (blk_overflow) cnt->max_start = 0xffffffffu;
     }
     __syncthreads();
     const unsigned long long g = blk_gbase;
     for (uint32_t i = threadIdx.x; i < nb; i += SCAN_THREADS)
         if (g + i < sig_cap) sig_out[g + i] = buf[i];
+}
+
+// Signature starts are < depth_len for coordinate-sorted input (start = pos + 1 <= contig length); the ordering pass sizes its
+// radix keys from this bound, and the scan raises ScanCounters::max_start to 0xffffffff if a start ever exceeds it.
+uint32_t scan_start_limit(uint32_t depth_len)
+{
+    int b = bits_of(depth_len);
+    if (b < 8) b = 8;
+    return b >= 32 ? 0xffffffffu : (1u << b);
 }
 
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
@@ -309,11 +350,12 @@ void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t dep
         blocks_per_cu = occ;
     }
     uint64_t want = (d.n_reads + SCAN_WAVES - 1) / SCAN_WAVES;
-    uint64_t cap = (uint64_t)n_cu * blocks_per_cu;
+    // two rounds of workgroups measured best (0.237 vs 0.247 ms at one round: the second round evens out the tail)
+    uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 2;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     hipLaunchKernelGGL(cigar_scan_kernel, dim3(grid), dim3(SCAN_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
-                       d.mapq, d.cigar_off, d.cigar, vec_ok, depth_len, min_oplen, min_mapq, emit, sig_out, sig_cap,
+                       d.mapq, d.cigar_off, d.cigar, vec_ok, depth_len, scan_start_limit(depth_len), min_oplen, min_mapq, emit, sig_out, sig_cap,
                        ref_end, q_start, q_end, ckpt, cnt);
 }
 
