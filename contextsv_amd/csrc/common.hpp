@@ -123,7 +123,8 @@ size_t prefix_max_tmp_bytes(uint64_t n);
 // ckpt: reference offset of the owning read at every 256-word CIGAR boundary (written by launch_cigar_scan).
 void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *pos_s,
                         const int32_t *ref_end, const int32_t *pmax_end, const uint32_t *ckpt, uint32_t depth_len,
-                        uint32_t *depth, ScanCounters *cnt);
+                        uint32_t *depth, ScanCounters *cnt, void *tmp /* depth_tiles_tmp_bytes(depth_len) */);
+size_t depth_tiles_tmp_bytes(uint32_t depth_len);
 static inline size_t ckpt_bytes(uint64_t n_cigar) { return ((n_cigar >> 8) + 2) * sizeof(uint32_t); }
 void launch_min_pts(hipStream_t s, ScanCounters *cnt, double min_pts_pct);
 // sort.hip

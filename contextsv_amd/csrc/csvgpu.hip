@@ -192,7 +192,8 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
     }
     int32_t *pmax = (int32_t *)arena_alloc(a, n * 4);
     void *ptmp = arena_alloc(a, prefix_max_tmp_bytes(n));
-    if (!pmax || !ptmp) { ctx->err = "arena exhausted (depth)"; return CSV_ENOMEM; }
+    void *ttmp = arena_alloc(a, depth_tiles_tmp_bytes(depth_len));
+    if (!pmax || !ptmp || !ttmp) { ctx->err = "arena exhausted (depth)"; return CSV_ENOMEM; }
     const uint32_t *ord = nullptr;
     const int32_t *pos_s = d.pos;
     const int32_t *end_s = ref_end;
@@ -209,12 +210,12 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
         ord = perm; pos_s = (const int32_t *)pos_g; end_s = (const int32_t *)end_g;
     }
     launch_prefix_max(ctx->stream, end_s, pmax, n, ptmp);
-    launch_depth_tiles(ctx->stream, d, ord, pos_s, ref_end, pmax, ckpt, depth_len, depth, cnt);
+    launch_depth_tiles(ctx->stream, d, ord, pos_s, ref_end, pmax, ckpt, depth_len, depth, cnt, ttmp);
     return CSV_OK;
 }
-static size_t depth_chain_bytes(uint64_t n)
+static size_t depth_chain_bytes(uint64_t n, uint32_t depth_len = 0xffffffffu)
 {
-    return align_up(n * 4, 256) + prefix_max_tmp_bytes(n) + sortws_bytes(n) + 2 * align_up(n * 4, 256) + 1024;
+    return depth_tiles_tmp_bytes(depth_len) + align_up(n * 4, 256) + prefix_max_tmp_bytes(n) + sortws_bytes(n) + 2 * align_up(n * 4, 256) + 1024;
 }
 
 // interval DBSCAN on device arrays in caller order
@@ -406,7 +407,7 @@ int csvgpu_depth(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, uint3
     }
     ScanCounters h;
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
-    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(reads->n_reads)))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(reads->n_reads, depth_len)))) return rc;
     if ((rc = depth_chain(ctx, ctx->work, dr.d, dr.ref_end, dr.ckpt, h.unsorted != 0, depth_len, d_depth, dr.cnt))) return rc;
     if (depth && depth_len) CSV_HIP(ctx, hipMemcpyAsync(depth, d_depth, (size_t)depth_len * 4, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
@@ -827,7 +828,7 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
     if (!sig_sorted || !st || !en || !labels || !ws_ok || !db_tmp) { ctx->err = "shard scratch exhausted"; return CSV_ENOMEM; }
 
     // depth map + mean coverage + min_pts (device scalar)
-    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads)))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads, sh->depth_len)))) return rc;
     if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, h.unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
     launch_min_pts(s, cnt, min_pts_pct);
 

@@ -27,6 +27,7 @@ constexpr int DEPTH_THREADS = 512;
 constexpr int DEPTH_WAVES = DEPTH_THREADS / WAVE;          // 8
 constexpr int DEPTH_PER_WAVE = DEPTH_TILE / DEPTH_WAVES;   // entries scanned per wave
 constexpr int DEPTH_ROUNDS = DEPTH_PER_WAVE / (4 * WAVE);  // rounds of 256 entries
+constexpr int WL_CAP = 256;                                // work-list items staged per batch (6 KiB of LDS)
 
 // ------------------------------------------------------------------------------- prefix max
 constexpr int PM_THREADS = 256;
@@ -116,27 +117,6 @@ void launch_prefix_max(hipStream_t s, const int32_t *in, int32_t *out, uint64_t 
 }
 
 // ------------------------------------------------------------------------------- depth tiles
-struct ReadMd {            // per-read metadata a wave needs, loaded one read ahead of use
-    uint64_t c0, c1;
-    uint32_t p1;           // 1-based first reference position (cnv_caller.cpp:498)
-    uint32_t ok;           // overlaps the tile and passes the depth filter
-};
-
-__device__ __forceinline__ ReadMd depth_load_md(uint64_t kk, uint64_t k_hi, const uint32_t *__restrict__ ord,
-                                                const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
-                                                const uint64_t *__restrict__ cigar_off, const int32_t *__restrict__ ref_end, uint64_t T0)
-{
-    ReadMd m; m.c0 = 0; m.c1 = 0; m.p1 = 0; m.ok = 0;
-    if (kk < k_hi) {
-        const uint64_t r = ord ? (uint64_t)ord[kk] : kk;
-        m.c0 = cigar_off[r]; m.c1 = cigar_off[r + 1];
-        m.p1 = (uint32_t)pos[r] + 1u;
-        const uint32_t fl = flag[r];
-        m.ok = ((int64_t)ref_end[r] >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP));   // cnv_caller.cpp:491-495
-    }
-    return m;
-}
-
 // first index i in [0, n] with a[i] >= target (a non-decreasing); 64-ary search by one wave
 __device__ __forceinline__ uint64_t wave_first_ge_i32(const int32_t *__restrict__ a, uint64_t n, int64_t target, int lane)
 {
@@ -173,12 +153,28 @@ __device__ __forceinline__ void depth_load4(const uint32_t *__restrict__ cigar, 
     }
 }
 
+// Candidate reads of every tile: reads cover 1-based positions [pos+1, ref_end]; tile t = [t*TILE, (t+1)*TILE) is touched by
+// reads k with pmax_end[k] >= T0 (prefix maximum of the read ends: first such k) and pos+1 < T1. One wave per tile, two
+// 64-ary searches, three dependent loads each — done once for all tiles so that no tile waits for it.
+__global__ __launch_bounds__(256) void depth_ranges_kernel(const int32_t *__restrict__ pos_s, const int32_t *__restrict__ pmax_end,
+                                                          uint64_t n_reads, uint32_t depth_len, uint32_t n_tiles,
+                                                          uint64_t *__restrict__ tile_range)
+{
+    const int lane = lane_id();
+    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const uint64_t T0 = (uint64_t)t * DEPTH_TILE;
+    const uint64_t T1 = min(T0 + (uint64_t)DEPTH_TILE, (uint64_t)depth_len);
+    const uint64_t lo = wave_first_ge_i32(pmax_end, n_reads, (int64_t)T0, lane);
+    const uint64_t hi = wave_first_ge_i32(pos_s, n_reads, (int64_t)T1 - 1, lane);
+    if (lane == 0) { tile_range[2 * (uint64_t)t] = lo; tile_range[2 * (uint64_t)t + 1] = hi; }
+}
+
 __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int vec_ok, int dvec_ok,
-    const uint32_t *__restrict__ ord,        // nullptr: reads already sorted by pos; else pos_s/pmax_end are in ord order
-    const int32_t *__restrict__ pos_s,       // positions in sorted order (== pos when ord == nullptr)
-    const int32_t *__restrict__ ref_end, const int32_t *__restrict__ pmax_end,
+    const uint32_t *__restrict__ ord,        // nullptr: reads already sorted by pos; else the tile ranges index `ord`
+    const int32_t *__restrict__ ref_end, const uint64_t *__restrict__ tile_range,
     const uint32_t *__restrict__ ckpt,       // reference offset of the owning read at every 256-word boundary (scan.hip)
     uint32_t depth_len, uint32_t *__restrict__ depth, ScanCounters *__restrict__ cnt)
 {
@@ -187,7 +183,10 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     __shared__ uint64_t range_s[2];
     __shared__ unsigned long long blk_sum;
     __shared__ unsigned int blk_nz;
-    __shared__ unsigned int next_read;
+    __shared__ unsigned int next_item, wl_n;
+    __shared__ uint64_t wl_chunk[WL_CAP];
+    __shared__ int32_t wl_c0rel[WL_CAP];
+    __shared__ uint32_t wl_nrem[WL_CAP], wl_p1[WL_CAP], wl_carry[WL_CAP];
 
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -195,84 +194,92 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     const uint64_t T1 = min(T0 + (uint64_t)DEPTH_TILE, (uint64_t)depth_len);
 
     for (int i = threadIdx.x; i < DEPTH_TILE + 4; i += DEPTH_THREADS) diff[i] = 0;
-    // reads cover 1-based positions [pos+1, ref_end]; candidates: pmax_end >= T0 and pos+1 < T1. Both bounds are found by
-    // 64-ary searches, one per wave, three dependent loads each (a one-thread binary search would hold the whole
-    // workgroup at this barrier for ~17 load latencies).
-    if (wave == 0) {
-        const uint64_t lo = wave_first_ge_i32(pmax_end, n_reads, (int64_t)T0, lane);
-        if (lane == 0) { range_s[0] = lo; next_read = 0; blk_sum = 0; blk_nz = 0; }
-    } else if (wave == 1) {
-        const uint64_t hi = wave_first_ge_i32(pos_s, n_reads, (int64_t)T1 - 1, lane);
-        if (lane == 0) range_s[1] = hi;
+    // candidate range of this tile, precomputed for all tiles by depth_ranges_kernel (one load instead of two searches)
+    if (threadIdx.x == 0) {
+        range_s[0] = tile_range[2 * (uint64_t)blockIdx.x]; range_s[1] = tile_range[2 * (uint64_t)blockIdx.x + 1];
+        blk_sum = 0; blk_nz = 0;
     }
     __syncthreads();
     const uint64_t k_lo = range_s[0], k_hi = max(range_s[0], range_s[1]);
 
-    // reads are handed to the waves through an LDS counter (their cost varies a lot: most candidates end left of the
-    // tile and are skipped, long ones take many chunks), with the next read's metadata already in flight
-    uint64_t kk = k_lo + depth_grab(&next_read, lane);
-    ReadMd md = depth_load_md(kk, k_hi, ord, pos, flag, cigar_off, ref_end, T0);
-    while (kk < k_hi) {
-        const ReadMd cur = md;
-        kk = k_lo + depth_grab(&next_read, lane);
-        md = depth_load_md(kk, k_hi, ord, pos, flag, cigar_off, ref_end, T0);
-        if (!cur.ok || cur.c1 <= cur.c0) continue;
-        const uint64_t c0 = cur.c0, c1 = cur.c1;
-        const uint64_t p1 = cur.p1;
-        // skip the chunks that lie left of the tile: all lanes fetch the read's checkpoints at once
-        uint64_t chunk = c0 & ~255ull;
-        uint64_t ref_carry = 0;
-        {
-            const uint64_t g0 = c0 >> 8, g1 = (c1 - 1) >> 8;
-            for (uint64_t gb = g0 + 1; gb <= g1; gb += WAVE) {
-                const uint64_t g = gb + lane;
-                uint32_t ck = 0; bool left = false;
-                if (g <= g1) { ck = ckpt[g]; left = p1 + ck <= T0; }
-                const uint64_t m = __ballot(left);
-                const int n_left = __popcll(m);                 // checkpoints are non-decreasing: `left` is a prefix
-                if (n_left) { chunk = (gb + n_left - 1) << 8; ref_carry = __shfl(ck, n_left - 1, 64); }
-                if (n_left < WAVE) break;
-            }
-        }
-        uint32_t w[4], w1[4], w2[4];
-        depth_load4(cigar, n_cigar, vec_ok, chunk + (uint64_t)lane * 4, w);
-        if (chunk + 4 * WAVE < c1) depth_load4(cigar, n_cigar, vec_ok, chunk + 4 * WAVE + (uint64_t)lane * 4, w1);
-        for (; chunk < c1; chunk += 4 * WAVE) {
-            if (p1 + ref_carry >= T1) break;                                   // rest of the read lies right of the tile
-            const uint64_t idx = chunk + (uint64_t)lane * 4;
-            const bool more = chunk + 4 * WAVE < c1;
-            if (chunk + 8 * WAVE < c1) depth_load4(cigar, n_cigar, vec_ok, idx + 8 * WAVE, w2);   // two chunks in flight ahead
-            uint32_t len[4], rl[4], aln = 0, lane_ref = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool valid = (idx + k >= c0) && (idx + k < c1);
-                const uint32_t op = valid ? (w[k] & 15u) : (uint32_t)OP_P;
-                len[k] = valid ? (w[k] >> 4) : 0u;
-                rl[k] = ((REF_OPS >> op) & 1u) ? len[k] : 0u;
-                aln |= ((ALN_OPS >> op) & 1u) << k;
-                lane_ref += rl[k];
-            }
-            const uint32_t incl = wave_incl_sum(lane_ref);
-            uint64_t a1 = p1 + ref_carry + (incl - lane_ref);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (((aln >> k) & 1u) && len[k]) {
-                    const uint64_t a = max(a1, T0), b = min(a1 + len[k], T1);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
-                    if (a < b) {
-                        atomicAdd(&diff[a - T0], 1u);
-                        atomicAdd(&diff[b - T0], 0xffffffffu);
-                    }
+    // Work list: the candidates are examined ONCE per tile by all threads together — thread t takes candidate t of the
+    // batch, loads its metadata (coalesced across threads), drops reads that end left of the tile or fail the depth filter
+    // (cnv_caller.cpp:491-495), and binary-searches the read's checkpoints for the last 256-word boundary left of the tile.
+    // Surviving (start chunk, reference carry, word range) items go to LDS; the waves then pull items from an LDS counter
+    // and go straight to CIGAR chunk loads, with no per-read metadata or checkpoint latency on their critical path.
+    for (uint64_t cb = k_lo; cb < k_hi; cb += WL_CAP) {
+        if (threadIdx.x == 0) { wl_n = 0; next_item = 0; }
+        __syncthreads();
+        const uint64_t kk = cb + threadIdx.x;
+        if (threadIdx.x < WL_CAP && kk < k_hi) {
+            const uint64_t r = ord ? (uint64_t)ord[kk] : kk;
+            const uint64_t c0 = cigar_off[r], c1 = cigar_off[r + 1];
+            const uint32_t fl = flag[r];
+            const bool ok = ((int64_t)ref_end[r] >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && c1 > c0;
+            if (ok) {
+                const uint64_t p1 = (uint64_t)(uint32_t)pos[r] + 1;                 // 1-based first reference position (:498)
+                const uint64_t g0 = c0 >> 8, g1 = (c1 - 1) >> 8;
+                uint64_t lo = g0 + 1, hi = g1 + 1;                                   // first boundary NOT left of the tile
+                while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (p1 + ckpt[mid] <= T0) lo = mid + 1; else hi = mid; }
+                uint64_t chunk = c0 & ~255ull; uint32_t carry = 0;
+                if (lo > g0 + 1) { chunk = (lo - 1) << 8; carry = ckpt[lo - 1]; }
+                if (p1 + carry < T1) {                                               // else the whole read lies right of the tile
+                    const uint32_t slot = atomicAdd(&wl_n, 1u);
+                    wl_chunk[slot] = chunk;
+                    wl_c0rel[slot] = (int32_t)((int64_t)c0 - (int64_t)chunk);        // first valid word, relative to the start chunk
+                    wl_nrem[slot] = (uint32_t)(c1 - chunk);                          // words from the start chunk to the read's end
+                    wl_p1[slot] = (uint32_t)p1;
+                    wl_carry[slot] = carry;
                 }
-                a1 += rl[k];
-            }
-            ref_carry += __shfl(incl, 63, 64);
-            if (more) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) { w[k] = w1[k]; w1[k] = w2[k]; }
             }
         }
+        __syncthreads();
+        const uint32_t n_items = wl_n;
+        for (uint32_t it = depth_grab(&next_item, lane); it < n_items; it = depth_grab(&next_item, lane)) {
+            const uint64_t chunk0 = wl_chunk[it];
+            const int32_t c0rel = wl_c0rel[it];
+            const uint32_t nrem = wl_nrem[it];
+            const uint64_t p1 = wl_p1[it];
+            uint64_t ref_carry = wl_carry[it];
+            uint32_t w[4], w1[4];
+            depth_load4(cigar, n_cigar, vec_ok, chunk0 + (uint64_t)lane * 4, w);
+            for (uint32_t o0 = 0; o0 < nrem; o0 += 4 * WAVE) {                      // o0: word offset of this chunk from chunk0
+                if (p1 + ref_carry >= T1) break;                                    // rest of the read lies right of the tile
+                const bool more = o0 + 4 * WAVE < nrem;
+                if (more) depth_load4(cigar, n_cigar, vec_ok, chunk0 + o0 + 4 * WAVE + (uint64_t)lane * 4, w1);   // next 1 KiB in flight
+                const int32_t o = (int32_t)o0 + lane * 4;
+                uint32_t len[4], rl[4], aln = 0, lane_ref = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool valid = (o + k >= c0rel) && ((uint32_t)(o + k) < nrem);
+                    const uint32_t op = valid ? (w[k] & 15u) : (uint32_t)OP_P;
+                    len[k] = valid ? (w[k] >> 4) : 0u;
+                    rl[k] = ((REF_OPS >> op) & 1u) ? len[k] : 0u;
+                    aln |= ((ALN_OPS >> op) & 1u) << k;
+                    lane_ref += rl[k];
+                }
+                const uint32_t incl = wave_incl_sum_dpp(lane_ref);
+                uint64_t a1 = p1 + ref_carry + (incl - lane_ref);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (((aln >> k) & 1u) && len[k]) {
+                        const uint64_t a = max(a1, T0), b = min(a1 + len[k], T1);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
+                        if (a < b) {
+                            atomicAdd(&diff[a - T0], 1u);
+                            atomicAdd(&diff[b - T0], 0xffffffffu);
+                        }
+                    }
+                    a1 += rl[k];
+                }
+                ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (more) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) w[k] = w1[k];
+                }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // scan the difference array: wave w owns entries [w*DEPTH_PER_WAVE, (w+1)*DEPTH_PER_WAVE)
     const int w_base = wave * DEPTH_PER_WAVE;
@@ -326,16 +333,20 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     }
 }
 
+size_t depth_tiles_tmp_bytes(uint32_t depth_len) { return align_up((((uint64_t)depth_len + DEPTH_TILE - 1) / DEPTH_TILE + 1) * 16, 256); }
+
 void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *pos_s,
                         const int32_t *ref_end, const int32_t *pmax_end, const uint32_t *ckpt, uint32_t depth_len,
-                        uint32_t *depth, ScanCounters *cnt)
+                        uint32_t *depth, ScanCounters *cnt, void *tmp)
 {
     if (depth_len == 0) return;
     const unsigned tiles = (unsigned)(((uint64_t)depth_len + DEPTH_TILE - 1) / DEPTH_TILE);
+    uint64_t *tile_range = (uint64_t *)tmp;
+    hipLaunchKernelGGL(depth_ranges_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, pos_s, pmax_end, d.n_reads, depth_len, tiles, tile_range);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     const int dvec_ok = (((uintptr_t)depth) & 15u) == 0;
     hipLaunchKernelGGL(depth_tile_kernel, dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
-                       d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, pos_s, ref_end, pmax_end, ckpt, depth_len, depth, cnt);
+                       d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt);
 }
 
 // min_pts = (int)ceil(mean_cov * pct), or 5 when pct <= 0 (sv_caller.cpp:723-728); mean = sum / #non-zero
