@@ -5,29 +5,33 @@
 //
 // The reference does ~30 x chromosome-length scalar increments. A read-owner GPU version would
 // need two scattered global atomics per M-run (~1.5e8 per chr22 at 30x, far below the HBM rate), so
-// the ownership is turned around: one workgroup owns one 8 Ki-position tile of the chromosome and
-// keeps the tile's DIFFERENCE array in LDS (32 KiB -> 4 workgroups, 32 waves per CU). It finds the
-// reads that overlap the tile by binary search (reads are coordinate-sorted; a prefix maximum of the
-// read ends bounds the search on the left); each wave takes reads from that range, skips the ones
-// that end left of the tile, jumps into the CIGAR at the last 256-word checkpoint left of the tile
-// (scan.hip records the reference offset of a read at every 256-word boundary; the checkpoints of a
-// read are fetched by all lanes in one load), walks 1 KiB chunks with the same 16-byte/lane wave scan
-// as scan.hip with the next chunk and the next read's metadata already in flight, applies +1/-1 with
-// LDS atomics, and stops at the tile's right edge. Finally the tile is scanned in LDS and depth is
-// written once, coalesced, 16 B per lane, while sum and non-zero count are accumulated. No global
-// atomics on the depth array, no memset, no separate scan pass. HBM traffic = CIGAR stream x (1 +
-// ~1 chunk per (tile, read) pair) + 4 B/base written.
+// the ownership is turned around: one 1024-thread workgroup owns one 16 Ki-position tile of the
+// chromosome and keeps the tile's DIFFERENCE array in LDS (64 KiB + a 12 KiB work list -> 2
+// workgroups = 32 waves per CU). Per tile:
+//   1. candidate reads = one precomputed range (depth_ranges_kernel: reads are coordinate-sorted; a
+//      prefix maximum of the read ends bounds the range on the left);
+//   2. all threads together build an LDS work list: thread t loads candidate t's metadata, drops reads
+//      that end left of the tile or fail the depth filter, and binary-searches the read's checkpoints
+//      (scan.hip records the reference offset of a read at every 256-word CIGAR boundary) for the last
+//      boundary left of the tile;
+//   3. waves pull items from an LDS counter and walk 1 KiB CIGAR chunks from that boundary (16-byte loads,
+//      one DPP wave scan per chunk, next chunk in flight), applying +1/-1 with LDS atomics, until the
+//      tile's right edge;
+//   4. the tile is scanned in LDS and depth is written once, coalesced, 16 B per lane, while sum and
+//      non-zero count are reduced.
+// No global atomics on the depth array, no memset, no separate scan pass. HBM traffic = CIGAR stream x
+// (1 + ~1 partial chunk per (tile, read) pair) + 4 B/base written.
 #include "../common.hpp"
 #include "../devutil.hpp"
 
 namespace csv {
 
-constexpr int DEPTH_TILE = 8192;
-constexpr int DEPTH_THREADS = 512;
+constexpr int DEPTH_TILE = 16384;
+constexpr int DEPTH_THREADS = 1024;
 constexpr int DEPTH_WAVES = DEPTH_THREADS / WAVE;          // 8
 constexpr int DEPTH_PER_WAVE = DEPTH_TILE / DEPTH_WAVES;   // entries scanned per wave
 constexpr int DEPTH_ROUNDS = DEPTH_PER_WAVE / (4 * WAVE);  // rounds of 256 entries
-constexpr int WL_CAP = 256;                                // work-list items staged per batch (6 KiB of LDS)
+constexpr int WL_CAP = 512;                                // work-list items staged per batch (12 KiB of LDS)
 
 // ------------------------------------------------------------------------------- prefix max
 constexpr int PM_THREADS = 256;
