@@ -72,6 +72,7 @@ ABI = {
     "csvgpu_aln_intervals_resident": (C.c_int, [_P, _P, _P, _P, _P]),
     "csvgpu_window_log2_resident": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_double, _P, _P, _P]),
     "csvgpu_chr_fetch": (C.c_int, [_P, _P, C.POINTER(csv_chr_result), _P, _P]),
+    "csvgpu_depth_lookup_resident": (C.c_int, [_P, _P, _P, C.c_uint64, _P]),
     "csvgpu_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "csvgpu_dbscan_iv_dev": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_double, C.c_int32, _P]),
     "csvgpu_dbscan_1d_dev": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_int32, _P]),

@@ -229,3 +229,10 @@ class Shard:
         if want_depth:
             out["depth"] = d2h(r.depth, self.depth_len * 4, np.uint32)
         return out
+
+    def depth_lookup(self, pos) -> np.ndarray:
+        """depth[pos[i]] on the resident depth map; -1 where pos[i] is outside it (csvgpu_depth_lookup_resident)."""
+        pos = np.ascontiguousarray(pos, np.uint32)
+        out = np.zeros(max(len(pos), 1), np.int32)
+        self.ctx._check(self.ctx.lib.csvgpu_depth_lookup_resident(self.ctx.h, self.h, ptr(pos), len(pos), ptr(out)))
+        return out[: len(pos)]

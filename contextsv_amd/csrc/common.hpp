@@ -127,6 +127,7 @@ void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, 
 size_t depth_tiles_tmp_bytes(uint32_t depth_len);
 static inline size_t ckpt_bytes(uint64_t n_cigar) { return ((n_cigar >> 8) + 2) * sizeof(uint32_t); }
 void launch_min_pts(hipStream_t s, ScanCounters *cnt, double min_pts_pct);
+void launch_depth_lookup(hipStream_t s, const uint32_t *depth, uint32_t depth_len, const uint32_t *pos, uint64_t n, int32_t *out);
 // sort.hip
 size_t radix_sort_tmp_bytes(uint64_t n);
 // stable LSD sort of (key,val) pairs by key bits [0,key_bits). Both buffer pairs are clobbered; returns 1 when the

@@ -761,6 +761,26 @@ int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *reg
     return CSV_OK;
 }
 
+int csvgpu_depth_lookup_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *pos, uint64_t n, int32_t *depth_out)
+{
+    if (!ctx || !sh) return CSV_EINVAL;
+    if (n == 0) return CSV_OK;
+    if (!pos || !depth_out) { ctx->err = "depth_lookup: null array"; return CSV_EINVAL; }
+    if (!sh->depth) { ctx->err = "depth_lookup: shard has no depth map (run csvgpu_chr_pipeline_dev first)"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    int rc = arena_reserve(ctx, ctx->arena, 2 * align_up(n * 4, 256) + 4096);
+    if (rc) return rc;
+    uint32_t *dpos = (uint32_t *)arena_alloc(ctx->arena, n * 4);
+    int32_t *dout = (int32_t *)arena_alloc(ctx->arena, n * 4);
+    if (!dpos || !dout) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    hipStream_t s = ctx->stream;
+    CSV_HIP(ctx, hipMemcpyAsync(dpos, pos, n * 4, hipMemcpyHostToDevice, s));
+    csv::launch_depth_lookup(s, sh->depth, sh->depth_len, dpos, n, dout);
+    CSV_HIP(ctx, hipMemcpyAsync(depth_out, dout, n * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipStreamSynchronize(s));
+    return CSV_OK;
+}
+
 int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *sh, const csv_chr_result *res, csv_sig *host_sig, int32_t *host_labels)
 {
     if (!ctx || !sh || !res) return CSV_EINVAL;

@@ -13,6 +13,9 @@
 #include "sort_select.h"
 #include "split_caller.h"
 #include "synth.h"
+#include "fasta_query.h"
+#include "vcf_writer.h"
+#include <fstream>
 #include <algorithm>
 #include <vector>
 
@@ -293,6 +296,9 @@ int csvhost_cn_prediction(csv_ctx *ctx, csv_shard *shard, int split, csvhost_cal
     })
 }
 
+struct csvhost_fasta;
+static const ReferenceGenome *fasta_genome(const csvhost_fasta *h);
+
 // ---- whole run (SVCaller::run mirror) over concatenated contig arrays -----------------------------
 // reads of contig t = [read_off[t], read_off[t+1]); cigar_off is global over the concatenated cigar array; SNPs of contig t =
 // [snp_off[t], snp_off[t+1]); qname of read i = "r<qname_id[i]>". Output: merged calls with contig id, contigs ascending.
@@ -300,7 +306,9 @@ int csvhost_run(csv_ctx *ctx, int n_contigs, const uint64_t *read_off, const uin
                 const uint8_t *mapq, const uint64_t *cigar_off, const uint32_t *cigar, const uint32_t *qname_id,
                 const uint64_t *snp_off, const uint32_t *snp_pos, const double *snp_baf, const double *snp_pfb, const uint8_t *snp_has,
                 const csv_hmm *hmm, double eps, double min_pts_pct, int sample_size, uint32_t min_cnv,
-                csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out)
+                csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out,
+                const csvhost_fasta *fasta, const char *vcf_dir, const char *gap_path, const char *file_date,
+                char *alt_buf, uint64_t alt_cap, uint64_t *alt_off)
 {
     GUARD({
         std::vector<ChromosomeInput> contigs((size_t)n_contigs);
@@ -322,10 +330,15 @@ int csvhost_run(csv_ctx *ctx, int n_contigs, const uint64_t *read_off, const uin
             c.depth_len = depth_len[t]; c.qnames = &qn[t]; c.snps = &tabs[t];
         }
         RunParams P; P.dbscan_epsilon = eps; P.dbscan_min_pts_pct = min_pts_pct; P.sample_size = sample_size; P.min_cnv_length = min_cnv;
+        if (fasta && vcf_dir) {
+            P.ref_genome = fasta_genome(fasta);
+            P.vcf.output_dir = vcf_dir; P.vcf.assembly_gaps = gap_path ? gap_path : ""; P.vcf.file_date = file_date ? file_date : "";
+        }
         SVCaller caller(ctx);
         std::unordered_map<std::string, std::vector<SVCall>> calls;
         caller.run(contigs, chmm_from_pod(hmm), P, calls);
-        uint64_t k = 0;
+        uint64_t k = 0, alt_used = 0;
+        if (alt_off) alt_off[0] = 0;
         for (int t = 0; t < n_contigs; t++) {
             for (const SVCall &c : calls[contigs[t].name]) {
                 if (k < cap) {
@@ -333,11 +346,106 @@ int csvhost_run(csv_ctx *ctx, int n_contigs, const uint64_t *read_off, const uin
                     p.start = c.start; p.end = c.end; p.sv_type = (int32_t)c.sv_type; p.cluster_size = c.cluster_size; p.hmm_likelihood = c.hmm_likelihood;
                     p.id = -1; p.aln_flags = (uint32_t)c.aln_type.to_ulong(); p.genotype = (int32_t)c.genotype; p.cn_state = c.cn_state; p.aln_offset = c.aln_offset;
                     out[k] = p; out_tid[k] = t;
+                    if (alt_off) {                     // ALT strings, concatenated; truncated once alt_cap is reached
+                        const uint64_t len = std::min<uint64_t>(c.alt_allele.size(), alt_cap - alt_used);
+                        if (alt_buf && len) memcpy(alt_buf + alt_used, c.alt_allele.data(), len);
+                        alt_used += len;
+                        alt_off[k + 1] = alt_used;
+                    }
                 }
                 k++;
             }
         }
         *n_out = k;
+    })
+}
+
+// ---- reference genome + VCF writer (fasta_query.cpp, saveToVCF) ---------------------------------------
+struct csvhost_fasta { ReferenceGenome g; };
+static const ReferenceGenome *fasta_genome(const csvhost_fasta *h) { return &h->g; }
+
+csvhost_fasta *csvhost_fasta_open(const char *path)
+{
+    try {
+        csvhost_fasta *h = new csvhost_fasta();
+        if (h->g.setFilepath(path ? path : "") != 0) { delete h; g_err = "No FASTA filepath provided"; return nullptr; }
+        return h;
+    } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+void csvhost_fasta_free(csvhost_fasta *h) { delete h; }
+
+// length of the view, -1 on error (unknown contig); at most cap bytes are copied to buf
+int64_t csvhost_fasta_query(const csvhost_fasta *h, const char *chr, uint32_t pos_start, uint32_t pos_end, char *buf, uint64_t cap)
+{
+    try {
+        std::string_view v = h->g.query(chr, pos_start, pos_end);
+        if (buf && cap) memcpy(buf, v.data(), (size_t)std::min<uint64_t>(cap, v.size()));
+        return (int64_t)v.size();
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+int csvhost_fasta_compare(const csvhost_fasta *h, const char *chr, uint32_t pos_start, uint32_t pos_end, const char *seq, float threshold)
+{
+    try { return h->g.compare(chr, pos_start, pos_end, seq, threshold) ? 1 : 0; } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+uint32_t csvhost_fasta_length(const csvhost_fasta *h, const char *chr) { return h->g.getChromosomeLength(chr); }
+// contig header and the sorted contig list ('\n'-joined) as text; returns the full length
+int64_t csvhost_fasta_contig_header(const csvhost_fasta *h, char *buf, uint64_t cap)
+{
+    const std::string s = h->g.getContigHeader();
+    if (buf && cap) memcpy(buf, s.data(), (size_t)std::min<uint64_t>(cap, s.size()));
+    return (int64_t)s.size();
+}
+int64_t csvhost_fasta_chromosomes(const csvhost_fasta *h, char *buf, uint64_t cap)
+{
+    std::string s;
+    for (const std::string &c : h->g.getChromosomes()) { if (!s.empty()) s += '\n'; s += c; }
+    if (buf && cap) memcpy(buf, s.data(), (size_t)std::min<uint64_t>(cap, s.size()));
+    return (int64_t)s.size();
+}
+
+// Calls of contig t = calls[call_off[t] .. call_off[t+1]) with ALT strings alts[i]. Depth comes from resident shards
+// (shards != nullptr, ShardDepthSource) or from host arrays depth[t][0..depth_len[t]) (a null depth[t] = contig without a map).
+// map_order != 0 goes through saveToVCF's unordered_map iteration; otherwise contigs are written in the order given.
+// counts = {total, unclassified, assembly-gap filtered}.
+int csvhost_save_vcf(csv_ctx *ctx, const char *out_dir, const csvhost_fasta *fasta, const char *gap_path, const char *file_date, int n_contigs,
+                     const char *const *chr_names, const uint64_t *call_off, const csvhost_call *calls, const char *const *alts,
+                     csv_shard *const *shards, const uint32_t *const *depth, const uint64_t *depth_len, int map_order, int32_t *counts)
+{
+    GUARD({
+        std::vector<std::pair<std::string, std::vector<SVCall>>> per((size_t)n_contigs);
+        std::unordered_map<std::string, std::vector<uint32_t>> host_depth;
+        ShardDepthSource shard_src(ctx);
+        for (int t = 0; t < n_contigs; t++) {
+            per[t].first = chr_names[t];
+            for (uint64_t i = call_off[t]; i < call_off[t + 1]; i++) {
+                SVCall c = from_pod(calls[i]);
+                c.alt_allele = alts[i];
+                per[t].second.push_back(c);
+            }
+            if (shards) { if (shards[t]) shard_src.add(chr_names[t], shards[t]); }
+            else if (depth[t]) host_depth[chr_names[t]].assign(depth[t], depth[t] + depth_len[t]);
+        }
+        HostDepthSource host_src(host_depth);
+        const DepthSource &src = shards ? (const DepthSource &)shard_src : (const DepthSource &)host_src;
+        VCFOptions opt;
+        opt.assembly_gaps = gap_path ? gap_path : "";
+        opt.output_dir = out_dir;
+        opt.file_date = file_date ? file_date : "";
+        VCFCounts c;
+        if (map_order) {
+            std::unordered_map<std::string, std::vector<SVCall>> m;
+            for (auto &e : per) m[e.first] = e.second;
+            if (!saveToVCF(m, opt, fasta->g, src, &c)) throw std::runtime_error("saveToVCF returned early");
+        } else {
+            std::unordered_map<std::string, std::vector<std::pair<uint32_t, uint32_t>>> gaps;
+            if (!opt.assembly_gaps.empty() && !loadAssemblyGaps(opt.assembly_gaps, gaps)) throw std::runtime_error("cannot open assembly gap file");
+            std::ofstream f(opt.output_dir + "/output.vcf");
+            if (!f.is_open()) throw std::runtime_error("cannot open output.vcf");
+            std::vector<std::pair<std::string, const std::vector<SVCall> *>> order;
+            for (auto &e : per) order.emplace_back(e.first, &e.second);
+            c = writeVCF(f, order, opt, gaps, fasta->g, src);
+        }
+        if (counts) { counts[0] = c.total; counts[1] = c.unclassified; counts[2] = c.assembly_gap_filtered; }
     })
 }
 

@@ -257,6 +257,12 @@ void SVCaller::run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm,
             printMessage("Total SVs detected for " + entry.first + ": " + std::to_string(getSVCount(entry.second)));
         }
         printMessage("Total SVs detected: " + std::to_string(total));
+        if (P.ref_genome && !P.vcf.output_dir.empty()) {                               // :943-945
+            printMessage("Saving SVs to VCF...");
+            ShardDepthSource depth(ctx);
+            for (size_t i = 0; i < contigs.size(); i++) if (shards[i]) depth.add(contigs[i].name, shards[i]);
+            saveToVCF(whole_genome_sv_calls, P.vcf, *P.ref_genome, depth);
+        }
     } catch (...) {
         free_all();
         throw;

@@ -15,6 +15,7 @@
 #include "khmm.h"
 #include "split_caller.h"
 #include "sv_object.h"
+#include "vcf_writer.h"
 
 // 4-bit packed read sequences (BAM encoding, two bases per byte, high nibble first); optional.
 struct SeqStore {
@@ -47,6 +48,8 @@ struct RunParams {
     int sample_size = 20;                   // --sample-size
     uint32_t min_cnv_length = 2000;         // --min-cnv
     bool cigar_svs = true, cigar_cn = true, split_svs = true, merge_split_svs = true, merge_final_svs = true;   // sv_caller.cpp:749-753
+    const ReferenceGenome *ref_genome = nullptr;   // with vcf.output_dir set: write <output_dir>/output.vcf at the end (sv_caller.cpp:943-945)
+    VCFOptions vcf;
 };
 
 class SVCaller {
@@ -78,7 +81,8 @@ public:
     // Pass ordering of SVCaller::run (sv_caller.cpp:747-946) over in-memory contigs: depth + CIGAR pass + CIGAR merge per
     // contig -> CIGAR copy-number predictions -> split-read signatures -> their copy-number predictions ->
     // mergeSVs(0.1, 2, keep_noise) on the split calls -> concatenation -> final mergeSVs(0.1, 2, keep_noise).
-    // Every contig's shard (reads, depth map) stays resident in HBM until the run ends. VCF output is not part of this path.
+    // Every contig's shard (reads, depth map) stays resident in HBM until the run ends; the VCF writer's SUPPORT / DP values are
+    // gathered from those resident maps.
     void run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm, const RunParams &params,
              std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls);
 

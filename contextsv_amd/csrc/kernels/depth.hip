@@ -367,4 +367,21 @@ void launch_min_pts(hipStream_t s, ScanCounters *cnt, double min_pts_pct)
     hipLaunchKernelGGL(min_pts_kernel, dim3(1), dim3(1), 0, s, cnt, min_pts_pct);
 }
 
+// depth[pos[i]] for a handful of positions (the VCF writer's SUPPORT / DP lookups, sv_caller.cpp:1306, :1332-1344);
+// -1 marks a position outside the map, which std::vector::at reports as out_of_range in the reference.
+__global__ void depth_lookup_kernel(const uint32_t *__restrict__ depth, uint32_t depth_len, const uint32_t *__restrict__ pos,
+                                    uint64_t n, int32_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = pos[i];
+    out[i] = p < depth_len ? (int32_t)depth[p] : -1;
+}
+
+void launch_depth_lookup(hipStream_t s, const uint32_t *depth, uint32_t depth_len, const uint32_t *pos, uint64_t n, int32_t *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(depth_lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, depth, depth_len, pos, n, out);
+}
+
 }  // namespace csv

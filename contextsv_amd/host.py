@@ -54,9 +54,22 @@ def load() -> C.CDLL:
                                           C.c_double, C.c_int, C.c_uint32, _P, _P, _P, _P, C.c_uint64]
     lib.csvhost_split_signatures.argtypes = [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_run.argtypes = [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_lib.csv_hmm), C.c_double, C.c_double,
-                                C.c_int, C.c_uint32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]
+                                C.c_int, C.c_uint32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), _P, C.c_char_p, C.c_char_p, C.c_char_p, _P, C.c_uint64, _P]
     lib.csvhost_read_chmm.argtypes = [C.c_char_p, C.POINTER(_lib.csv_hmm), C.POINTER(C.c_int32)]
     lib.csvhost_sort_select_check.argtypes = [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.csvhost_fasta_open.restype = _P
+    lib.csvhost_fasta_open.argtypes = [C.c_char_p]
+    lib.csvhost_fasta_free.argtypes = [_P]
+    lib.csvhost_fasta_query.restype = C.c_int64
+    lib.csvhost_fasta_query.argtypes = [_P, C.c_char_p, C.c_uint32, C.c_uint32, _P, C.c_uint64]
+    lib.csvhost_fasta_compare.argtypes = [_P, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_float]
+    lib.csvhost_fasta_length.restype = C.c_uint32
+    lib.csvhost_fasta_length.argtypes = [_P, C.c_char_p]
+    lib.csvhost_fasta_contig_header.restype = C.c_int64
+    lib.csvhost_fasta_contig_header.argtypes = [_P, _P, C.c_uint64]
+    lib.csvhost_fasta_chromosomes.restype = C.c_int64
+    lib.csvhost_fasta_chromosomes.argtypes = [_P, _P, C.c_uint64]
+    lib.csvhost_save_vcf.argtypes = [_P, C.c_char_p, _P, C.c_char_p, C.c_char_p, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -226,9 +239,11 @@ def split_signatures(ctx: Context, tid, pos, flag, mapq, ref_end, q_start, q_end
     return out[: k.value].copy()
 
 
-def run(ctx: Context, contigs: list, hmm, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000):
-    """SVCaller::run mirror. contigs: list of dicts {reads: Reads, depth_len, qname_id: uint32[n], snps: dict}.
-    -> (merged calls, contig id per call)."""
+def run(ctx: Context, contigs: list, hmm, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, genome=None, vcf_dir=None,
+        gap_path=None, file_date=None, want_alts=False):
+    """SVCaller::run mirror. contigs: list of dicts {reads: Reads, depth_len, qname_id: uint32[n], snps: dict}; contig t is named
+    "contig<t>". With genome (ReferenceGenome) and vcf_dir the run ends by writing <vcf_dir>/output.vcf.
+    -> (merged calls, contig id per call[, ALT strings])."""
     read_off = np.zeros(len(contigs) + 1, np.uint64)
     read_off[1:] = np.cumsum([c["reads"].n_reads for c in contigs])
     cig_base = np.concatenate([[0], np.cumsum([c["reads"].n_cigar for c in contigs])]).astype(np.uint64)
@@ -249,10 +264,20 @@ def run(ctx: Context, contigs: list, hmm, eps=0.1, min_pts_pct=0.1, sample_size=
     out = np.zeros(cap, CALL_DTYPE)
     tid = np.zeros(cap, np.int32)
     n = C.c_uint64(0)
+    alt_cap = 64 * cap if want_alts else 0
+    alt_buf = np.zeros(max(alt_cap, 1), np.uint8)
+    alt_off = np.zeros(cap + 1, np.uint64)
     _check(load().csvhost_run(ctx.h, len(contigs), read_off.ctypes.data, dl.ctypes.data, pos.ctypes.data, flag.ctypes.data, mapq.ctypes.data,
                               coff.ctypes.data, cigar.ctypes.data, qid.ctypes.data, snp_off.ctypes.data, sp.ctypes.data, sb.ctypes.data,
                               sf.ctypes.data, sh.ctypes.data, C.byref(hmm), eps, min_pts_pct, sample_size, min_cnv, out.ctypes.data,
-                              tid.ctypes.data, cap, C.byref(n)))
+                              tid.ctypes.data, cap, C.byref(n),
+                              genome.h if genome is not None and vcf_dir else None, os.fsencode(vcf_dir) if vcf_dir else None,
+                              os.fsencode(gap_path) if gap_path else None, file_date.encode() if file_date else None,
+                              alt_buf.ctypes.data if want_alts else None, alt_cap, alt_off.ctypes.data if want_alts else None))
+    if want_alts:
+        raw = alt_buf.tobytes()
+        alts = [raw[int(alt_off[i]):int(alt_off[i + 1])] for i in range(n.value)]
+        return out[: n.value].copy(), tid[: n.value].copy(), alts
     return out[: n.value].copy(), tid[: n.value].copy()
 
 
@@ -269,3 +294,84 @@ def read_chmm(path: str):
     n = C.c_int32(0)
     _check(load().csvhost_read_chmm(path.encode(), C.byref(h), C.byref(n)))
     return h, n.value
+
+
+class ReferenceGenome:
+    """ReferenceGenome of the host mirror (src/fasta_query.cpp): whole FASTA in memory, 1-based inclusive queries."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self.h = load().csvhost_fasta_open(os.fsencode(path))
+        if not self.h:
+            raise RuntimeError((load().csvhost_last_error() or b"cannot open FASTA").decode())
+
+    def close(self):
+        if self.h:
+            load().csvhost_fasta_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _text(self, fn) -> bytes:
+        n = fn(self.h, None, 0)
+        buf = C.create_string_buffer(max(int(n), 1))
+        fn(self.h, buf, n)
+        return buf.raw[:n]
+
+    def query(self, chr: str, pos_start: int, pos_end: int) -> bytes:
+        """Raises KeyError for an unknown contig (std::out_of_range in the C++ interface)."""
+        lib = load()
+        n = lib.csvhost_fasta_query(self.h, chr.encode(), pos_start, pos_end, None, 0)
+        if n < 0:
+            raise KeyError(chr)
+        buf = C.create_string_buffer(max(int(n), 1))
+        lib.csvhost_fasta_query(self.h, chr.encode(), pos_start, pos_end, buf, n)
+        return buf.raw[:n]
+
+    def compare(self, chr: str, pos_start: int, pos_end: int, seq: bytes, threshold: float) -> bool:
+        rc = load().csvhost_fasta_compare(self.h, chr.encode(), pos_start, pos_end, seq, threshold)
+        if rc < 0:
+            raise KeyError(chr)
+        return bool(rc)
+
+    def getChromosomeLength(self, chr: str) -> int:
+        return int(load().csvhost_fasta_length(self.h, chr.encode()))
+
+    def getContigHeader(self) -> bytes:
+        return self._text(load().csvhost_fasta_contig_header)
+
+    def getChromosomes(self):
+        t = self._text(load().csvhost_fasta_chromosomes)
+        return t.split(b"\n") if t else []
+
+
+def save_vcf(out_dir: str, genome: ReferenceGenome, contigs, gap_path: str | None = None, file_date: str | None = None,
+             ctx: Context | None = None, map_order: bool = False):
+    """saveToVCF (host mirror) -> <out_dir>/output.vcf. `contigs` = [(name, calls[CALL_DTYPE], alts[list of bytes], depth)] where depth is a
+    resident Shard (SUPPORT/DP gathered on the device; needs ctx), a uint32 numpy array, or None. Returns (total, unclassified, gap_filtered)."""
+    lib = load()
+    n = len(contigs)
+    names = (C.c_char_p * n)(*[c[0].encode() for c in contigs])
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum([len(c[1]) for c in contigs])
+    calls = np.ascontiguousarray(np.concatenate([np.asarray(c[1], CALL_DTYPE) for c in contigs]) if n else np.zeros(0, CALL_DTYPE))
+    alt_list = [a for c in contigs for a in c[2]]
+    assert len(alt_list) == len(calls)
+    alts = (C.c_char_p * max(len(alt_list), 1))(*alt_list)
+    use_shards = n > 0 and all(hasattr(c[3], "h") or c[3] is None for c in contigs) and any(c[3] is not None for c in contigs)
+    keep = []
+    if use_shards:
+        shards = (C.c_void_p * n)(*[(c[3].h if c[3] is not None else None) for c in contigs])
+        depth_p, len_p, shard_p = None, None, shards
+    else:
+        arrs = [(np.ascontiguousarray(c[3], np.uint32) if c[3] is not None else None) for c in contigs]
+        keep.append(arrs)
+        dptr = (C.c_void_p * max(n, 1))(*[(a.ctypes.data if a is not None else None) for a in arrs])
+        dlen = np.array([(len(a) if a is not None else 0) for a in arrs] + [0], np.uint64)
+        depth_p, len_p, shard_p = dptr, dlen.ctypes.data, None
+    counts = np.zeros(3, np.int32)
+    _check(lib.csvhost_save_vcf(ctx.h if ctx is not None else None, os.fsencode(out_dir), genome.h, os.fsencode(gap_path) if gap_path else None,
+                                file_date.encode() if file_date else None, n, names, off.ctypes.data, calls.ctypes.data, alts,
+                                shard_p, depth_p, len_p, int(map_order), counts.ctypes.data))
+    return tuple(int(x) for x in counts)

@@ -236,6 +236,10 @@ int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *
                                 const int32_t *sample_size, const uint64_t *win_off, uint64_t n_regions, double mean_cov,
                                 double *log2_cov, uint32_t *win_start, uint32_t *win_end);
 
+/* depth_out[i] = depth[pos[i]] on the depth map resident in `shard`, or -1 where pos[i] >= depth_len: the VCF writer's
+ * SUPPORT / DP lookups (SVCaller::getReadDepth, sv_caller.cpp:1332-1344, called at :1306) without moving the map. */
+int csvgpu_depth_lookup_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *pos, uint64_t n, int32_t *depth_out);
+
 /* Copy `bytes` from device memory returned by this library (csv_chr_result pointers) to host memory;
  * synchronous with respect to the context's stream. For host code above the ABI that does not link HIP. */
 int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);

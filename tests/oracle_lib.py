@@ -53,6 +53,50 @@ class Oracle:
         lib.orc_merge_svs.argtypes = [P, C.c_uint64, C.c_double, C.c_int32, C.c_int, LABEL_FN, P]
         lib.orc_merge_duplicates.restype = C.c_int64
         lib.orc_merge_duplicates.argtypes = [P, C.c_uint64]
+        lib.orc_fasta_query.restype = C.c_int64
+        lib.orc_fasta_query.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, P, C.c_uint64]
+        lib.orc_fasta_describe.restype = C.c_int64
+        lib.orc_fasta_describe.argtypes = [C.c_char_p, P, C.c_uint64]
+        lib.orc_save_vcf.restype = C.c_int
+        lib.orc_save_vcf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, P, P, P, P, P, P, P]
+
+    def fasta_query(self, fasta, chr, a, b):
+        """ReferenceGenome::query restated; None for an unknown contig."""
+        n = self.lib.orc_fasta_query(fasta.encode(), chr.encode(), a, b, None, 0)
+        if n == -1:
+            return None
+        assert n >= 0, n
+        buf = C.create_string_buffer(max(int(n), 1))
+        self.lib.orc_fasta_query(fasta.encode(), chr.encode(), a, b, buf, n)
+        return buf.raw[:n]
+
+    def fasta_describe(self, fasta):
+        """(getContigHeader, getChromosomes) restated."""
+        n = self.lib.orc_fasta_describe(fasta.encode(), None, 0)
+        assert n >= 0, n
+        buf = C.create_string_buffer(max(int(n), 1))
+        self.lib.orc_fasta_describe(fasta.encode(), buf, n)
+        hdr, names = buf.raw[:n].split(b"\x01")
+        return hdr, (names.split(b"\n") if names else [])
+
+    def save_vcf(self, out_path, fasta, contigs, gap_path=None, file_date=None):
+        """saveToVCF restated. contigs = [(name, calls[48-byte POD], alts, depth uint32 array or None)]. Returns (rc, counts)."""
+        n = len(contigs)
+        names = (C.c_char_p * max(n, 1))(*[c[0].encode() for c in contigs])
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum([len(c[1]) for c in contigs])
+        calls = np.ascontiguousarray(np.concatenate([c[1] for c in contigs])) if n else np.zeros(0, np.uint8)
+        assert calls.dtype.itemsize == 48
+        alt_list = [a for c in contigs for a in c[2]]
+        alts = (C.c_char_p * max(len(alt_list), 1))(*alt_list)
+        arrs = [(np.ascontiguousarray(c[3], np.uint32) if c[3] is not None else None) for c in contigs]
+        dptr = (C.c_void_p * max(n, 1))(*[(a.ctypes.data if a is not None else None) for a in arrs])
+        dlen = np.array([(len(a) if a is not None else 0) for a in arrs] + [0], np.uint64)
+        counts = np.zeros(3, np.int32)
+        rc = self.lib.orc_save_vcf(out_path.encode(), fasta.encode(), gap_path.encode() if gap_path else None,
+                                   file_date.encode() if file_date else None, n, names, off.ctypes.data, calls.ctypes.data, alts,
+                                   dptr, dlen.ctypes.data, counts.ctypes.data)
+        return rc, tuple(int(x) for x in counts)
 
     def cigar_scan(self, reads, depth_len, min_oplen=50, min_mapq=20):
         cap = max(reads.n_cigar, 1)

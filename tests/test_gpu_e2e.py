@@ -104,10 +104,25 @@ def _orc_merge(oracle, full, eps, min_pts, keep_noise):
     return out
 
 
-def test_whole_path_end_to_end(ctx, oracle):
+def _write_genome(path, n_contigs, rng):
+    with open(path, "wb") as f:
+        for t in range(n_contigs):
+            f.write(b">contig%d synthetic\n" % t)
+            seq = np.frombuffer(b"ACGTNRacgt", np.uint8)[rng.choice(10, CONTIG_LEN, p=[.24, .24, .24, .24, .01, .01, .005, .005, .005, .005])]
+            f.write(b"\n".join(seq[i:i + 60].tobytes() for i in range(0, CONTIG_LEN, 60)) + b"\n")
+
+
+def test_whole_path_end_to_end(ctx, oracle, tmp_path):
     contigs = _build(7)
     hmm = make_hmm(**WGS_HMM)
-    got, got_tid = host.run(ctx, contigs, hmm, eps=0.1, min_pts_pct=0.1)
+    fasta = str(tmp_path / "genome.fa")
+    _write_genome(fasta, len(contigs), np.random.default_rng(1))
+    gaps = str(tmp_path / "gaps.bed")
+    with open(gaps, "w") as f:
+        f.write("contig0\t100000\t400000\ncontig2\t0\t50000\n")
+    genome = host.ReferenceGenome(fasta)
+    got, got_tid, got_alts = host.run(ctx, contigs, hmm, eps=0.1, min_pts_pct=0.1, genome=genome, vcf_dir=str(tmp_path), gap_path=gaps,
+                                      file_date="20250926", want_alts=True)
 
     # ---- the same chain from the oracle's pieces --------------------------------------------------
     cigar_calls, depths, means = [], [], []
@@ -146,3 +161,17 @@ def test_whole_path_end_to_end(ctx, oracle):
     np.testing.assert_allclose(got["hmm_likelihood"], exp["hmm_likelihood"], rtol=0, atol=1e-6)
     assert (got["cn_state"] != 0).any() and (got["aln_flags"] & (1 << 8)).any()       # the HMM did update calls
     assert ((got["aln_flags"] & (1 << 3)) != 0).any() or ((got["aln_flags"] & (1 << 4)) != 0).any()   # split evidence survived the merges
+
+    # ---- the VCF the run wrote (SUPPORT / DP gathered from the resident depth maps) against the oracle's writer fed with the
+    # oracle's depth maps; contig order in the file is the unordered_map's, so compare per contig
+    items = [("contig%d" % t, got[got_tid == t], [a for a, tt in zip(got_alts, got_tid) if tt == t], depths[t]) for t in range(len(contigs))]
+    rc, counts = oracle.save_vcf(str(tmp_path / "oracle.vcf"), fasta, items, gap_path=gaps, file_date="20250926")
+    assert rc == 0 and counts[0] > 20 and counts[2] > 0
+    got_lines = (tmp_path / "output.vcf").read_text().split("\n")
+    exp_lines = (tmp_path / "oracle.vcf").read_text().split("\n")
+    assert [l for l in got_lines if l.startswith("#")] == [l for l in exp_lines if l.startswith("#")]
+    for t in range(len(contigs)):
+        pre = "contig%d\t" % t
+        assert [l for l in got_lines if l.startswith(pre)] == [l for l in exp_lines if l.startswith(pre)]
+    assert len(got_lines) == len(exp_lines)
+    assert any("\tAssemblyGap\t" in l for l in got_lines) and any("SVTYPE=DEL" in l for l in got_lines) and any("SVTYPE=INS" in l for l in got_lines)
