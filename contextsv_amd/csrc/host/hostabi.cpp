@@ -15,6 +15,7 @@
 #include "synth.h"
 #include "fasta_query.h"
 #include "vcf_writer.h"
+#include "bam_io.h"
 #include <fstream>
 #include <algorithm>
 #include <vector>
@@ -446,6 +447,160 @@ int csvhost_save_vcf(csv_ctx *ctx, const char *out_dir, const csvhost_fasta *fas
             c = writeVCF(f, order, opt, gaps, fasta->g, src);
         }
         if (counts) { counts[0] = c.total; counts[1] = c.unclassified; counts[2] = c.assembly_gap_filtered; }
+    })
+}
+
+// ---- BAM / BAI reader and writer (bam_io) --------------------------------------------------------------
+struct csvhost_bam { BamReader r; std::vector<BamShard> shards; std::string names; };
+
+csvhost_bam *csvhost_bam_open(const char *path, int load_index)
+{
+    csvhost_bam *h = new csvhost_bam();
+    if (!h->r.open(path) || (load_index && !h->r.loadIndex())) { g_err = h->r.error(); delete h; return nullptr; }
+    for (const std::string &n : h->r.header().names) { if (!h->names.empty()) h->names += '\n'; h->names += n; }
+    return h;
+}
+void csvhost_bam_close(csvhost_bam *h) { delete h; }
+int csvhost_bam_n_ref(const csvhost_bam *h) { return (int)h->r.header().names.size(); }
+const char *csvhost_bam_names(const csvhost_bam *h) { return h->names.c_str(); }
+const char *csvhost_bam_text(const csvhost_bam *h) { return h->r.header().text.c_str(); }
+uint32_t csvhost_bam_ref_len(const csvhost_bam *h, int tid) { return h->r.header().lens[(size_t)tid]; }
+
+// chr != nullptr: readContig (needs the index) -> one shard; chr == nullptr: readAll -> one shard per contig with records.
+// Returns the number of shards now held by the handle (replacing the previous ones), or -1.
+int csvhost_bam_read(csvhost_bam *h, const char *chr, int want_seq, int want_qnames, int threads, uint32_t window_blocks, uint64_t *n_unplaced)
+{
+    try {
+        BamReadOptions opt;
+        opt.want_seq = want_seq != 0; opt.want_qnames = want_qnames != 0; opt.threads = threads;
+        if (window_blocks) opt.window_blocks = window_blocks;
+        h->shards.clear();
+        bool ok;
+        if (chr) { h->shards.emplace_back(); ok = h->r.readContig(chr, opt, h->shards.back()); }
+        else ok = h->r.readAll(opt, [&](BamShard &&s) { h->shards.push_back(std::move(s)); }, n_unplaced);
+        if (!ok) { g_err = h->r.error(); h->shards.clear(); return -1; }
+        return (int)h->shards.size();
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+// view of shard i: arrays stay owned by the handle until the next read / close
+void csvhost_bam_shard(const csvhost_bam *h, int i, csv_reads *reads, int32_t *tid, uint32_t *target_len, const uint64_t **seq_off, const uint8_t **seq)
+{
+    const BamShard &s = h->shards[(size_t)i];
+    *reads = s.view();
+    *tid = s.tid; *target_len = s.target_len;
+    *seq_off = s.seq_off.data(); *seq = s.seq.data();
+}
+// query names of shard i, '\n'-joined; returns the text length (copying at most cap bytes)
+int64_t csvhost_bam_shard_qnames(const csvhost_bam *h, int i, char *buf, uint64_t cap)
+{
+    std::string t;
+    for (const std::string &q : h->shards[(size_t)i].qnames) { t += q; t += '\n'; }
+    if (buf && cap) memcpy(buf, t.data(), (size_t)std::min<uint64_t>(cap, t.size()));
+    return (int64_t)t.size();
+}
+
+// Write a coordinate-sorted BAM + BAI from arrays. qnames: '\n'-separated (one per record). seq_off / seq may be null (l_seq = 0);
+// l_seq[i] gives the base count (the packed length alone cannot tell odd from even).
+int csvhost_bam_write(const char *path, const char *text, int n_ref, const char *ref_names, const uint32_t *ref_lens, uint64_t n, const int32_t *tid,
+                      const int32_t *pos, const uint16_t *flag, const uint8_t *mapq, const uint64_t *cigar_off, const uint32_t *cigar,
+                      const char *qnames, const uint64_t *seq_off, const uint8_t *seq, const int32_t *l_seq, int level, int threads)
+{
+    GUARD({
+        BamHeader hd;
+        hd.text = text ? text : "";
+        const char *p = ref_names;
+        for (int i = 0; i < n_ref; i++) {
+            const char *e = strchr(p, '\n');
+            hd.names.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+            hd.lens.push_back(ref_lens[i]);
+            p = e ? e + 1 : p + strlen(p);
+        }
+        BamWriter w;
+        if (!w.open(path, hd, level, threads)) throw std::runtime_error(w.error());
+        const char *q = qnames;
+        for (uint64_t i = 0; i < n; i++) {
+            const char *e = strchr(q, '\n');
+            std::string name(q, e ? (size_t)(e - q) : strlen(q));
+            q = e ? e + 1 : q + strlen(q);
+            const int32_t ls = (seq && l_seq) ? l_seq[i] : 0;
+            w.add(tid[i], pos[i], mapq[i], flag[i], name, cigar + cigar_off[i], (uint32_t)(cigar_off[i + 1] - cigar_off[i]),
+                  ls ? seq + seq_off[i] : nullptr, ls, nullptr);
+        }
+        if (!w.close()) throw std::runtime_error(w.error());
+    })
+}
+
+// The synthetic shard as a coordinate-sorted BAM + BAI on one contig ("stage inputs ... as a real BGZF BAM + BAI").
+// Query names are r<index>; sequences are written when the shard has them, else l_seq = 0 ("*").
+int csvhost_synth_write_bam(const csvhost_synth *h, const char *path, const char *chr_name, int level, int threads, uint64_t *bam_bytes)
+{
+    GUARD({
+        const SynthShard &sh = h->sh;
+        BamHeader hd;
+        hd.text = std::string("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:") + chr_name + "\tLN:" + std::to_string(sh.depth_len - 1) + "\n";
+        hd.names.push_back(chr_name);
+        hd.lens.push_back(sh.depth_len - 1);
+        BamWriter w;
+        if (!w.open(path, hd, level, threads)) throw std::runtime_error(w.error());
+        const bool have_seq = !sh.seq.empty() && sh.seq_off.size() == sh.pos.size() + 1;
+        // the generator emits reads in position order per thread slice and merges them sorted; verify rather than assume
+        for (size_t i = 0; i < sh.pos.size(); i++) {
+            if (i && sh.pos[i] < sh.pos[i - 1]) throw std::runtime_error("synthetic shard is not coordinate-sorted");
+            const uint32_t *cg = sh.cigar.data() + sh.cigar_off[i];
+            const uint32_t nc = (uint32_t)(sh.cigar_off[i + 1] - sh.cigar_off[i]);
+            int32_t l_seq = 0;
+            if (have_seq) for (uint32_t k = 0; k < nc; k++) if ((0x3C1A7u >> ((cg[k] & 15) << 1)) & 1) l_seq += (int32_t)(cg[k] >> 4);   // query-consuming ops
+            w.add(0, sh.pos[i], sh.mapq[i], sh.flag[i], "r" + std::to_string(i), cg, nc, have_seq ? sh.seq.data() + sh.seq_off[i] : nullptr, l_seq, nullptr);
+        }
+        if (!w.close()) throw std::runtime_error(w.error());
+        if (bam_bytes) { bgzf::MappedFile f; std::string e; *bam_bytes = f.open(path, &e) ? f.size() : 0; }
+    })
+}
+
+struct csvhost_bam_stats { uint64_t n_contigs, n_reads, n_cigar, bam_bytes; double ms_decode, ms_total; };
+
+// SVCaller::runBam: chrs = '\n'-separated contig names or null (all). SNPs: none (every window gets the dummy observation).
+// Calls come back grouped by contig in header order, with their contig index in out_tid.
+int csvhost_run_bam(csv_ctx *ctx, const char *bam_path, const char *chrs, int threads, const csv_hmm *hmm, double eps, double min_pts_pct,
+                    int sample_size, uint32_t min_cnv, int split_svs, const csvhost_fasta *fasta, const char *vcf_dir, const char *gap_path,
+                    const char *file_date, csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out, csvhost_bam_stats *stats)
+{
+    GUARD({
+        std::vector<std::string> list;
+        for (const char *p = chrs; p && *p;) {
+            const char *e = strchr(p, '\n');
+            list.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+            p = e ? e + 1 : p + strlen(p);
+        }
+        RunParams P; P.dbscan_epsilon = eps; P.dbscan_min_pts_pct = min_pts_pct; P.sample_size = sample_size; P.min_cnv_length = min_cnv;
+        P.split_svs = split_svs != 0;
+        if (fasta && vcf_dir) {
+            P.ref_genome = fasta_genome(fasta);
+            P.vcf.output_dir = vcf_dir; P.vcf.assembly_gaps = gap_path ? gap_path : ""; P.vcf.file_date = file_date ? file_date : "";
+        }
+        SVCaller caller(ctx);
+        std::unordered_map<std::string, std::vector<SVCall>> calls;
+        BamRunStats bs;
+        caller.runBam(bam_path, list, threads, chmm_from_pod(hmm), P, calls, &bs);
+        BamReader hdr_reader;
+        if (!hdr_reader.open(bam_path)) throw std::runtime_error(hdr_reader.error());
+        uint64_t k = 0;
+        for (size_t t = 0; t < hdr_reader.header().names.size(); t++) {
+            auto it = calls.find(hdr_reader.header().names[t]);
+            if (it == calls.end()) continue;
+            for (const SVCall &c : it->second) {
+                if (k < cap) {
+                    csvhost_call p;
+                    p.start = c.start; p.end = c.end; p.sv_type = (int32_t)c.sv_type; p.cluster_size = c.cluster_size; p.hmm_likelihood = c.hmm_likelihood;
+                    p.id = -1; p.aln_flags = (uint32_t)c.aln_type.to_ulong(); p.genotype = (int32_t)c.genotype; p.cn_state = c.cn_state; p.aln_offset = c.aln_offset;
+                    out[k] = p; out_tid[k] = (int32_t)t;
+                }
+                k++;
+            }
+        }
+        *n_out = k;
+        if (stats) { stats->n_contigs = bs.n_contigs; stats->n_reads = bs.n_reads; stats->n_cigar = bs.n_cigar; stats->bam_bytes = bs.bam_bytes;
+                     stats->ms_decode = bs.ms_decode; stats->ms_total = bs.ms_total; }
     })
 }
 

@@ -37,10 +37,11 @@ SVCall SVCaller::toSVCall(const csv_sig &s, const SeqStore *seq)
     std::string alt = "<INS>";
     if (op_len <= 50) {
         alt.assign(op_len, 'N');
-        if (seq && seq->seq && seq->seq_off) {
+        const uint32_t q0 = CSV_SIG_QPOS(s);
+        // a record stored without its sequence ("*", l_seq = 0) has nothing to copy from: the ALT stays N's
+        if (seq && seq->seq && seq->seq_off && ((uint64_t)q0 + op_len + 1) / 2 <= seq->seq_off[s.read + 1] - seq->seq_off[s.read]) {
             static const char nt16[] = "=ACMGRSVTWYHKDBN";              // BAM 4-bit code table (SAM spec §4.2.3)
             const uint8_t *p = seq->seq + seq->seq_off[s.read];
-            const uint32_t q0 = CSV_SIG_QPOS(s);
             for (uint32_t j = 0; j < op_len; j++) {
                 const uint32_t q = q0 + j;
                 const char b = nt16[(p[q >> 1] >> ((~q & 1u) << 2)) & 0xf];
@@ -191,23 +192,60 @@ struct EmptySnps : SNPSource {
 };
 }  // namespace
 
+namespace {
+struct VectorSource : ContigSource {
+    explicit VectorSource(const std::vector<ChromosomeInput> &v) : v(v) {}
+    bool next(ChromosomeInput &out) override { if (i >= v.size()) return false; out = v[i++]; return true; }
+    const std::vector<ChromosomeInput> &v;
+    size_t i = 0;
+};
+}  // namespace
+
 void SVCaller::run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm, const RunParams &P,
+                   std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls)
+{
+    VectorSource src(contigs);
+    run(src, hmm, P, whole_genome_sv_calls);
+}
+
+void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
                    std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls)
 {
     csvhost::set_context(ctx);
     const EmptySnps no_snps;
-    std::vector<csv_shard *> shards(contigs.size(), nullptr);
-    std::vector<ChrStats> stats(contigs.size());
+    // what outlives a contig's host arrays: its shard (reads, depth map, alignment intervals in HBM), its statistics, its SNP
+    // source, and the 28 bytes + query name per record that the split-read pass groups by
+    std::vector<std::string> names;
+    std::vector<csv_shard *> shards;
+    std::vector<ChrStats> stats;
+    std::vector<const SNPSource *> snps;
+    std::vector<SplitRecord> records;
+    std::vector<std::string> qnames;
     std::unordered_map<std::string, size_t> index_of;
     auto free_all = [&] { for (csv_shard *s : shards) if (s) csvgpu_shard_free(ctx, s); };
     try {
         // depth pass + CIGAR pass + CIGAR merge (sv_caller.cpp:794-863); the reference pre-seeds the map with every contig
-        for (size_t i = 0; i < contigs.size(); i++) {
-            const ChromosomeInput &c = contigs[i];
+        ChromosomeInput c;
+        while (source.next(c)) {
+            const size_t i = names.size();
+            names.push_back(c.name);
+            shards.push_back(nullptr);
+            stats.emplace_back();
+            snps.push_back(c.snps);
             index_of[c.name] = i;
             std::vector<SVCall> calls;
             if (P.cigar_svs) processChromosome(c.name, c.reads, c.seq, c.depth_len, P.dbscan_epsilon, P.dbscan_min_pts_pct, calls, stats[i], &shards[i]);
             whole_genome_sv_calls[c.name] = std::move(calls);
+            if (P.split_svs && c.qnames && shards[i]) {                                 // inputs of the split-read pass (:133-175)
+                const uint64_t n = c.reads.n_reads;
+                std::vector<int32_t> ref_end(n), q_start(n), q_end(n);
+                check(ctx, csvgpu_aln_intervals_resident(ctx, shards[i], ref_end.data(), q_start.data(), q_end.data()), "alignment intervals");
+                records.reserve(records.size() + n);
+                for (uint64_t r = 0; r < n; r++) {
+                    records.push_back(SplitRecord{(int32_t)i, c.reads.pos[r], c.reads.flag[r], c.reads.mapq[r], ref_end[r], q_start[r], q_end[r]});
+                    qnames.push_back((*c.qnames)[r]);
+                }
+            }
         }
         CNVCaller cnv(ctx);
         cnv.sample_size = P.sample_size; cnv.min_cnv_length = P.min_cnv_length;
@@ -217,32 +255,18 @@ void SVCaller::run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm,
                 if (entry.second.empty()) continue;
                 const size_t i = index_of.at(entry.first);
                 cnv.runCIGARCopyNumberPrediction(entry.first, entry.second, hmm, stats[i].mean_chr_cov, shards[i],
-                                                 contigs[i].snps ? *contigs[i].snps : (const SNPSource &)no_snps);
+                                                 snps[i] ? *snps[i] : (const SNPSource &)no_snps);
             }
         }
         if (P.split_svs) {                                                             // :885-917
-            std::vector<SplitRecord> records;
-            std::vector<std::string> qnames, targets;
-            for (size_t i = 0; i < contigs.size(); i++) {
-                const ChromosomeInput &c = contigs[i];
-                targets.push_back(c.name);
-                if (!c.qnames || !shards[i]) continue;
-                const uint64_t n = c.reads.n_reads;
-                std::vector<int32_t> ref_end(n), q_start(n), q_end(n);
-                check(ctx, csvgpu_aln_intervals_resident(ctx, shards[i], ref_end.data(), q_start.data(), q_end.data()), "alignment intervals");
-                for (uint64_t r = 0; r < n; r++) {
-                    records.push_back(SplitRecord{(int32_t)i, c.reads.pos[r], c.reads.flag[r], c.reads.mapq[r], ref_end[r], q_start[r], q_end[r]});
-                    qnames.push_back((*c.qnames)[r]);
-                }
-            }
             std::unordered_map<std::string, std::vector<SVCall>> split_calls;
             SplitParams sp; sp.min_mapq = min_mapq;
-            findSplitSVSignatures(records, qnames, targets, sp, split_calls);
+            findSplitSVSignatures(records, qnames, names, sp, split_calls);
             for (auto &entry : split_calls) {
                 if (entry.second.empty()) continue;
                 const size_t i = index_of.at(entry.first);
                 cnv.runSplitReadCopyNumberPredictions(entry.first, entry.second, hmm, stats[i].mean_chr_cov, shards[i],
-                                                      contigs[i].snps ? *contigs[i].snps : (const SNPSource &)no_snps);
+                                                      snps[i] ? *snps[i] : (const SNPSource &)no_snps);
             }
             if (P.merge_split_svs) for (auto &entry : split_calls) mergeSVs(entry.second, 0.1, 2, true);
             for (auto &entry : split_calls) {
@@ -260,7 +284,7 @@ void SVCaller::run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm,
         if (P.ref_genome && !P.vcf.output_dir.empty()) {                               // :943-945
             printMessage("Saving SVs to VCF...");
             ShardDepthSource depth(ctx);
-            for (size_t i = 0; i < contigs.size(); i++) if (shards[i]) depth.add(contigs[i].name, shards[i]);
+            for (size_t i = 0; i < names.size(); i++) if (shards[i]) depth.add(names[i], shards[i]);
             saveToVCF(whole_genome_sv_calls, P.vcf, *P.ref_genome, depth);
         }
     } catch (...) {
@@ -268,4 +292,75 @@ void SVCaller::run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm,
         throw;
     }
     free_all();
+}
+
+// ---- the run fed from a BAM file ----------------------------------------------------------------------------------
+#include <future>
+
+#include "bam_io.h"
+
+namespace {
+// Contigs decoded one ahead: while run() has contig i on the device, the inflate pool works on contig i + 1.
+struct BamSource : ContigSource {
+    BamReader reader;
+    std::vector<std::string> chrs;
+    BamReadOptions opt;
+    BamShard cur, ahead;
+    std::future<bool> pending;
+    SeqStore seq;
+    size_t i = 0;
+    BamRunStats st;
+
+    void launch(size_t k) { pending = std::async(std::launch::async, [this, k] { return reader.readContig(chrs[k], opt, ahead); }); }
+
+    bool next(ChromosomeInput &out) override
+    {
+        if (i >= chrs.size()) return false;
+        const double t0 = now_ms();
+        if (!pending.valid()) launch(i);
+        const bool ok = pending.get();
+        st.ms_decode += now_ms() - t0;
+        if (!ok) throw std::runtime_error(reader.error());
+        std::swap(cur, ahead);
+        if (i + 1 < chrs.size()) launch(i + 1);
+        seq.seq_off = cur.seq_off.data();
+        seq.seq = cur.seq.data();
+        out = ChromosomeInput();
+        out.name = cur.name;
+        out.reads = cur.view();
+        out.seq = opt.want_seq ? &seq : nullptr;
+        out.depth_len = cur.target_len + 1;                       // cnv_caller.cpp:482
+        out.qnames = opt.want_qnames ? &cur.qnames : nullptr;
+        st.n_contigs++; st.n_reads += cur.n_reads(); st.n_cigar += cur.cigar.size();
+        i++;
+        return true;
+    }
+    ~BamSource() override { if (pending.valid()) pending.wait(); }
+};
+}  // namespace
+
+void SVCaller::runBam(const std::string &bam_path, const std::vector<std::string> &chromosomes, int threads, const CHMM &hmm, const RunParams &P,
+                      std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, BamRunStats *bam_stats)
+{
+    const double t0 = now_ms();
+    BamSource src;
+    if (!src.reader.open(bam_path)) throw std::runtime_error("ERROR failed to open BAM file " + bam_path + ": " + src.reader.error());
+    if (!src.reader.loadIndex()) throw std::runtime_error("ERROR failed to load index for " + bam_path);
+    src.chrs = chromosomes.empty() ? src.reader.header().names : chromosomes;      // sv_caller.cpp:766-774
+    for (const std::string &chr : src.chrs) {
+        if (src.reader.header().tid(chr) < 0) throw std::runtime_error("ERROR: Could not find chromosome " + chr + " in BAM file.");
+        if (P.ref_genome && P.ref_genome->getChromosomeLength(chr) == 0) {        // :795-800: the reference gives up on the whole run
+            printError("Chromosome " + chr + " not found in reference genome");
+            return;
+        }
+    }
+    src.opt.threads = std::max(1, threads);
+    src.opt.want_seq = true;                                      // 50-bp insertion ALT strings (sv_caller.cpp:589-600)
+    src.opt.want_qnames = P.split_svs;
+    run(src, hmm, P, whole_genome_sv_calls);
+    if (bam_stats) {
+        *bam_stats = src.st;
+        bam_stats->bam_bytes = src.reader.bytes();
+        bam_stats->ms_total = now_ms() - t0;
+    }
 }

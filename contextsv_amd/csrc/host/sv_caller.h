@@ -42,6 +42,14 @@ struct ChromosomeInput {
     const SNPSource *snps = nullptr;        // nullptr: no SNPs (every window gets the dummy observation)
 };
 
+// Contigs one at a time: next() fills `out` and returns false at the end. The arrays behind `out` (reads, sequences, query
+// names) only have to stay valid until the following call — run() uploads them and keeps what it needs; `out.snps` must live
+// until run() returns.
+struct ContigSource {
+    virtual ~ContigSource() = default;
+    virtual bool next(ChromosomeInput &out) = 0;
+};
+
 struct RunParams {
     double dbscan_epsilon = 0.1;            // --eps          (input_data.cpp:18-37)
     double dbscan_min_pts_pct = 0.1;        // --min-pts-pct
@@ -50,6 +58,12 @@ struct RunParams {
     bool cigar_svs = true, cigar_cn = true, split_svs = true, merge_split_svs = true, merge_final_svs = true;   // sv_caller.cpp:749-753
     const ReferenceGenome *ref_genome = nullptr;   // with vcf.output_dir set: write <output_dir>/output.vcf at the end (sv_caller.cpp:943-945)
     VCFOptions vcf;
+};
+
+struct BamRunStats {
+    uint64_t n_contigs = 0, n_reads = 0, n_cigar = 0, bam_bytes = 0;
+    double ms_decode = 0.0;          // wall time spent waiting for decoded contigs (decode not hidden behind the device)
+    double ms_total = 0.0;
 };
 
 class SVCaller {
@@ -85,6 +99,15 @@ public:
     // gathered from those resident maps.
     void run(const std::vector<ChromosomeInput> &contigs, const CHMM &hmm, const RunParams &params,
              std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls);
+    void run(ContigSource &source, const CHMM &hmm, const RunParams &params,
+             std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls);
+
+    // The same run fed from a coordinate-sorted, indexed BAM (reference: SVCaller::run(const InputData&) opening the file three
+    // times per contig, sv_caller.cpp:747-863): each contig is decoded once by BamReader (threads = inflate threads) while the
+    // previous one is on the device. chromosomes empty = every contig of the header (the reference's default), else the listed
+    // ones (--chr). The contig length is the BAM header's (cnv_caller.cpp:482).
+    void runBam(const std::string &bam_path, const std::vector<std::string> &chromosomes, int threads, const CHMM &hmm, const RunParams &params,
+                std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, struct BamRunStats *bam_stats = nullptr);
 
     // signature -> SVCall with the reference's field values (sv_caller.cpp:569-643)
     static SVCall toSVCall(const csv_sig &s, const SeqStore *seq);

@@ -22,6 +22,11 @@ class chr_stats(C.Structure):
                 ("ms_host_merge", C.c_double), ("n_calls", C.c_uint64)]
 
 
+class bam_stats(C.Structure):
+    _fields_ = [("n_contigs", C.c_uint64), ("n_reads", C.c_uint64), ("n_cigar", C.c_uint64), ("bam_bytes", C.c_uint64),
+                ("ms_decode", C.c_double), ("ms_total", C.c_double)]
+
+
 _P = C.c_void_p
 _hlib = None
 
@@ -70,6 +75,25 @@ def load() -> C.CDLL:
     lib.csvhost_fasta_chromosomes.restype = C.c_int64
     lib.csvhost_fasta_chromosomes.argtypes = [_P, _P, C.c_uint64]
     lib.csvhost_save_vcf.argtypes = [_P, C.c_char_p, _P, C.c_char_p, C.c_char_p, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]
+    lib.csvhost_bam_open.restype = _P
+    lib.csvhost_bam_open.argtypes = [C.c_char_p, C.c_int]
+    lib.csvhost_bam_close.argtypes = [_P]
+    lib.csvhost_bam_n_ref.argtypes = [_P]
+    lib.csvhost_bam_names.restype = C.c_char_p
+    lib.csvhost_bam_names.argtypes = [_P]
+    lib.csvhost_bam_text.restype = C.c_char_p
+    lib.csvhost_bam_text.argtypes = [_P]
+    lib.csvhost_bam_ref_len.restype = C.c_uint32
+    lib.csvhost_bam_ref_len.argtypes = [_P, C.c_int]
+    lib.csvhost_bam_read.argtypes = [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.csvhost_bam_shard.argtypes = [_P, C.c_int, C.POINTER(_lib.csv_reads), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P)]
+    lib.csvhost_bam_shard_qnames.restype = C.c_int64
+    lib.csvhost_bam_shard_qnames.argtypes = [_P, C.c_int, _P, C.c_uint64]
+    lib.csvhost_bam_write.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, _P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_char_p, _P, _P, _P,
+                                      C.c_int, C.c_int]
+    lib.csvhost_synth_write_bam.argtypes = [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    lib.csvhost_run_bam.argtypes = [_P, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_lib.csv_hmm), C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int,
+                                    _P, C.c_char_p, C.c_char_p, C.c_char_p, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(bam_stats)]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -157,6 +181,12 @@ class SynthShard:
         self.reads.cigar_off = view(r.cigar_off, n + 1, np.uint64)
         self.reads.cigar = view(r.cigar, m, np.uint32)
         self.seq_off_ptr, self.seq_ptr = so.value, sq.value
+
+    def write_bam(self, path: str, chr_name: str = "chr22", level: int = 1, threads: int = 8) -> int:
+        """The shard as a coordinate-sorted BAM + BAI on one contig; returns the BAM's size in bytes."""
+        nbytes = C.c_uint64(0)
+        _check(load().csvhost_synth_write_bam(self.h, os.fsencode(path), chr_name.encode(), level, threads, C.byref(nbytes)))
+        return nbytes.value
 
     def free(self):
         if self.h:
@@ -375,3 +405,99 @@ def save_vcf(out_dir: str, genome: ReferenceGenome, contigs, gap_path: str | Non
                                 file_date.encode() if file_date else None, n, names, off.ctypes.data, calls.ctypes.data, alts,
                                 shard_p, depth_p, len_p, int(map_order), counts.ctypes.data))
     return tuple(int(x) for x in counts)
+
+
+def _np_from(ptr_, count, dtype):
+    if not ptr_ or count == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr_)
+    return np.frombuffer(buf, dtype).copy()
+
+
+class BamFile:
+    """BamReader of the host mirror (BGZF/BAM/BAI without htslib). Shards come back as dicts of numpy arrays
+    {tid, name, target_len, reads: Reads, seq_off, seq, qnames}."""
+
+    def __init__(self, path: str, load_index: bool = True):
+        self.h = load().csvhost_bam_open(os.fsencode(path), int(load_index))
+        if not self.h:
+            raise RuntimeError((load().csvhost_last_error() or b"cannot open BAM").decode())
+        lib = load()
+        n = lib.csvhost_bam_n_ref(self.h)
+        names = lib.csvhost_bam_names(self.h).decode()
+        self.names = names.split("\n") if n else []
+        self.lens = [int(lib.csvhost_bam_ref_len(self.h, i)) for i in range(n)]
+        self.text = lib.csvhost_bam_text(self.h).decode()
+
+    def close(self):
+        if self.h:
+            load().csvhost_bam_close(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _shard(self, i, want_seq, want_qnames):
+        lib = load()
+        rs, tid, tl, so, sq = _lib.csv_reads(), C.c_int32(0), C.c_uint32(0), C.c_void_p(), C.c_void_p()
+        lib.csvhost_bam_shard(self.h, i, C.byref(rs), C.byref(tid), C.byref(tl), C.byref(so), C.byref(sq))
+        n, m = rs.n_reads, rs.n_cigar
+        addr = lambda p: C.cast(p, C.c_void_p).value
+        reads = Reads.__new__(Reads)
+        reads.pos, reads.flag, reads.mapq, reads.tid = _np_from(addr(rs.pos), n, np.int32), _np_from(addr(rs.flag), n, np.uint16), _np_from(addr(rs.mapq), n, np.uint8), None
+        reads.cigar_off, reads.cigar = _np_from(addr(rs.cigar_off), n + 1, np.uint64), _np_from(addr(rs.cigar), m, np.uint32)
+        out = {"tid": tid.value, "name": self.names[tid.value], "target_len": tl.value, "reads": reads}
+        if want_seq:
+            out["seq_off"] = _np_from(so.value, n + 1, np.uint64)
+            out["seq"] = _np_from(sq.value, int(out["seq_off"][-1]), np.uint8)
+        if want_qnames:
+            ln = lib.csvhost_bam_shard_qnames(self.h, i, None, 0)
+            buf = C.create_string_buffer(max(int(ln), 1))
+            lib.csvhost_bam_shard_qnames(self.h, i, buf, ln)
+            out["qnames"] = buf.raw[:ln].decode().split("\n")[:-1]
+        return out
+
+    def read_contig(self, chr: str, want_seq=False, want_qnames=False, threads=8, window_blocks=0):
+        k = load().csvhost_bam_read(self.h, chr.encode(), int(want_seq), int(want_qnames), threads, window_blocks, None)
+        if k < 0:
+            raise RuntimeError((load().csvhost_last_error() or b"BAM read failed").decode())
+        return self._shard(0, want_seq, want_qnames)
+
+    def read_all(self, want_seq=False, want_qnames=False, threads=8, window_blocks=0):
+        un = C.c_uint64(0)
+        k = load().csvhost_bam_read(self.h, None, int(want_seq), int(want_qnames), threads, window_blocks, C.byref(un))
+        if k < 0:
+            raise RuntimeError((load().csvhost_last_error() or b"BAM read failed").decode())
+        return [self._shard(i, want_seq, want_qnames) for i in range(k)], un.value
+
+
+def write_bam(path: str, ref_names, ref_lens, tid, reads: Reads, qnames, seq_off=None, seq=None, l_seq=None, text="", level=1, threads=4):
+    """BamWriter of the host mirror: coordinate-sorted records -> <path> + <path>.bai."""
+    n = reads.n_reads
+    tid = np.ascontiguousarray(tid, np.int32)
+    lens = np.ascontiguousarray(ref_lens, np.uint32)
+    pos, flag, mapq = (np.ascontiguousarray(a, t) for a, t in ((reads.pos, np.int32), (reads.flag, np.uint16), (reads.mapq, np.uint8)))
+    coff, cig = np.ascontiguousarray(reads.cigar_off, np.uint64), np.ascontiguousarray(reads.cigar, np.uint32)
+    assert len(qnames) == n
+    so = np.ascontiguousarray(seq_off, np.uint64) if seq_off is not None else None
+    sq = np.ascontiguousarray(seq, np.uint8) if seq is not None else None
+    ls = np.ascontiguousarray(l_seq, np.int32) if l_seq is not None else None
+    p = lambda a: a.ctypes.data if a is not None else None
+    _check(load().csvhost_bam_write(os.fsencode(path), text.encode(), len(ref_names), "\n".join(ref_names).encode(), p(lens), n, p(tid), p(pos), p(flag),
+                                    p(mapq), p(coff), p(cig), "\n".join(qnames).encode(), p(so), p(sq), p(ls), level, threads))
+
+
+def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True,
+            genome: ReferenceGenome | None = None, vcf_dir=None, gap_path=None, file_date=None, capacity: int = 1 << 20):
+    """SVCaller::runBam: the whole run fed from a coordinate-sorted, indexed BAM. -> (calls, contig index per call, stats dict)."""
+    out = np.zeros(capacity, CALL_DTYPE)
+    tid = np.zeros(capacity, np.int32)
+    n = C.c_uint64(0)
+    st = bam_stats()
+    _check(load().csvhost_run_bam(ctx.h, os.fsencode(bam_path), "\n".join(chromosomes).encode() if chromosomes else None, threads, C.byref(hmm), eps,
+                                  min_pts_pct, sample_size, min_cnv, int(split_svs), genome.h if genome is not None and vcf_dir else None,
+                                  os.fsencode(vcf_dir) if vcf_dir else None, os.fsencode(gap_path) if gap_path else None,
+                                  file_date.encode() if file_date else None, out.ctypes.data, tid.ctypes.data, capacity, C.byref(n), C.byref(st)))
+    if n.value > capacity:
+        raise RuntimeError("run_bam: capacity too small")
+    return out[: n.value].copy(), tid[: n.value].copy(), {f: getattr(st, f) for f, _ in bam_stats._fields_}
