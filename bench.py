@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--eps", type=float, default=0.1)
     ap.add_argument("--min-pts-pct", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-from-file", action="store_true", help="skip the BAM-staged from-file measurement")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after the other (step latency)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0, help="fraction of the shard's reads given to the CPU baseline")
     args = ap.parse_args()
@@ -179,6 +180,8 @@ def main():
                          "all": {k: {"ms": round(kern.get(k, 0.0), 5), "GBps": round(alg_bytes[k] / (kern[k] * 1e-3) / 1e9, 2) if kern.get(k, 0) > 0 else None}
                                  for k in alg_bytes}},
         }
+        if world == 1 and not args.no_from_file:
+            out["from_file"] = from_file(ctx, syn, args, st)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(reads, depth_len, args, st)
         print(json.dumps(out), flush=True)
@@ -191,10 +194,42 @@ def main():
         dist.destroy_process_group()
 
 
+def from_file(ctx, syn, args, st):
+    """SURVEY §8d's from-file number: the same shard staged as a real coordinate-sorted BGZF BAM + BAI, then one contig end to end
+    through SVCaller::runBam — BGZF inflate on the host cores + BAM record decode + H2D + device chain + host merge. Never `value`:
+    it is bound by zlib on the host, not by the GPU."""
+    import tempfile
+    from contextsv_amd import host, make_hmm
+    threads = min(os.cpu_count() or 8, 16)               # the box's CPU share for one GPU
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+        bam = os.path.join(d, "shard.bam")
+        t0 = time.perf_counter()
+        nbytes = syn.write_bam(bam, "chr22", level=1, threads=threads)
+        t_write = time.perf_counter() - t0
+        hmm = make_hmm(A=np.full((6, 6), 1 / 6.0), pi=np.full(6, 1 / 6.0), B1_mean=np.zeros(6), B1_sd=np.ones(6), B1_uf=0.01,
+                       B2_mean=np.zeros(5), B2_sd=np.ones(5), B2_uf=0.01)      # unused: the copy-number pass is off
+        best = None
+        for _ in range(2):                                                      # second pass: page cache warm, as a re-run would be
+            t0 = time.perf_counter()
+            calls, _, bs = host.run_bam(ctx, bam, hmm, chromosomes=["chr22"], threads=threads, eps=args.eps, min_pts_pct=args.min_pts_pct,
+                                        split_svs=False, cigar_cn=False)
+            t = time.perf_counter() - t0
+            if best is None or t < best[0]:
+                best = (t, bs, len(calls))
+    t, bs, n_calls = best
+    return {"reads_per_s": bs["n_reads"] / t, "seconds": round(t, 4), "decode_wait_s": round(bs["ms_decode"] * 1e-3, 4),
+            "bam_bytes": int(nbytes), "bam_write_s": round(t_write, 3), "inflate_threads": threads, "merged_calls": int(n_calls),
+            "compressed_GBps": nbytes / t / 1e9,
+            "note": "BGZF inflate (zlib) + BAM decode + upload + device chain + merge for one contig; sequences not stored (l_seq = 0)"}
+
+
 def cpu_baseline(reads, depth_len, args, st):
-    """The CPU restatement (oracle, kind "port") timed on this host, single thread, on a bounded sample of
-    the same workload: the first `frac` of the shard's reads through scan -> depth -> per-type O(n^2) DBSCAN
-    (the reference's structure: three passes, brute-force regionQuery)."""
+    """The CPU restatement (oracle, kind "port") timed on this host on a bounded sample of the same workload: the first `frac`
+    of the shard's reads through scan -> depth -> per-type O(n^2) DBSCAN (the reference's structure: three passes, brute-force
+    regionQuery). The reference parallelises over chromosomes, one thread each (sv_caller.cpp:827-863), so the multi-thread
+    figure runs one such sample per thread concurrently (ctypes releases the GIL) and reports the aggregate; `value` is the
+    better of the two, `cores` the thread count it was reached with."""
+    import threading
     import oracle_lib
     from contextsv_amd import Reads
     orc = oracle_lib.load_oracle()
@@ -203,24 +238,48 @@ def cpu_baseline(reads, depth_len, args, st):
     sub = Reads.__new__(Reads)
     sub.pos, sub.flag, sub.mapq, sub.tid = reads.pos[:n], reads.flag[:n], reads.mapq[:n], None
     sub.cigar_off, sub.cigar = reads.cigar_off[: n + 1], reads.cigar[:m]
-    t0 = time.perf_counter()
-    sig = orc.cigar_scan(sub, depth_len)
-    t1 = time.perf_counter()
-    _, s, nz = orc.depth(sub, depth_len)
-    t2 = time.perf_counter()
-    mean = s / nz if nz else 0.0
-    min_pts = int(np.ceil(mean * args.min_pts_pct)) if args.min_pts_pct > 0 else 5
-    kind = sig["qpos_kind"] & 3
-    for sel in (kind == 1, kind != 1):
-        part = sig[sel]
-        if len(part) >= 2 and min_pts >= 1:
-            orc.dbscan_iv(part["start"], part["end"], args.eps, min_pts)
-    t3 = time.perf_counter()
-    total = t3 - t0
-    return {"value": n / total, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} of {reads.n_reads} reads of the same shard ({m} CIGAR ops, {len(sig)} signatures): "
-                      f"scan {t1 - t0:.2f}s + depth {t2 - t1:.2f}s + O(n^2) DBSCAN {t3 - t2:.2f}s, oracle/csv_oracle.c -O2, 1 thread",
-            "signatures_clustered_per_s": len(sig) / total, "seconds": total}
+
+    def one(res):
+        t0 = time.perf_counter()
+        sig = orc.cigar_scan(sub, depth_len)
+        t1 = time.perf_counter()
+        _, s, nz = orc.depth(sub, depth_len)
+        t2 = time.perf_counter()
+        mean = s / nz if nz else 0.0
+        min_pts = int(np.ceil(mean * args.min_pts_pct)) if args.min_pts_pct > 0 else 5
+        kind = sig["qpos_kind"] & 3
+        for sel in (kind == 1, kind != 1):
+            part = sig[sel]
+            if len(part) >= 2 and min_pts >= 1:
+                orc.dbscan_iv(part["start"], part["end"], args.eps, min_pts)
+        t3 = time.perf_counter()
+        res.append((t1 - t0, t2 - t1, t3 - t2, len(sig)))
+
+    r1 = []
+    one(r1)
+    scan_s, depth_s, db_s, n_sig = r1[0]
+    total1 = scan_s + depth_s + db_s
+    v1 = n / total1
+    threads = max(1, min(os.cpu_count() or 1, 24))           # 24 contigs = the reference's useful maximum
+    vt = 0.0
+    if threads > 1:
+        rs, ts = [], []
+        t0 = time.perf_counter()
+        for _ in range(threads):
+            th = threading.Thread(target=one, args=(rs,))
+            th.start()
+            ts.append(th)
+        for th in ts:
+            th.join()
+        wall = time.perf_counter() - t0
+        vt = threads * n / wall
+    best, cores = (vt, threads) if vt > v1 else (v1, 1)
+    return {"value": best, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} of {reads.n_reads} reads of the same shard ({m} CIGAR ops, {n_sig} signatures) per thread: "
+                      f"scan {scan_s:.2f}s + depth {depth_s:.2f}s + O(n^2) DBSCAN {db_s:.2f}s at 1 thread, oracle/csv_oracle.c -O2; "
+                      f"{threads} threads = {threads} such samples concurrently (one contig per thread, as the reference schedules)",
+            "value_1_thread": v1, "value_all_threads": vt, "threads_tried": threads, "host_cpus": os.cpu_count(),
+            "signatures_clustered_per_s": n_sig * best / n, "seconds_1_thread": total1}
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <future>
 #include <map>
+#include <thread>
 
 namespace {
 inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -213,10 +214,23 @@ bool BamReader::loadIndex(const std::string &index_path)
     return true;
 }
 
-// Decompressed record stream from a virtual offset: batches of blocks are inflated by the pool while the previous batch is parsed.
-bool BamReader::stream(uint64_t start_voffset, const BamReadOptions &opt, const std::function<bool(const uint8_t *, uint32_t)> &on_record)
+namespace {
+// run fn(t) for t in [0, nt) on nt threads (the caller's included)
+template <class F>
+void parallel_chunks(int nt, F fn)
 {
-    struct Batch { std::vector<bgzf::Block> blocks; std::vector<uint8_t> data; size_t head = 0; bool ok = true; std::string err; uint64_t next_coff = 0; };
+    if (nt <= 1) { fn(0); return; }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(fn, t);
+    fn(0);
+    for (auto &t : pool) t.join();
+}
+}  // namespace
+
+// Decompressed record stream from a virtual offset: batches of blocks are inflated by the pool while the previous batch is parsed.
+bool BamReader::stream(uint64_t start_voffset, const BamReadOptions &opt, const std::function<size_t(const RecRef *, size_t)> &on_batch)
+{
+    struct Batch { std::vector<bgzf::Block> blocks; HugeVec<uint8_t> data; size_t head = 0; bool ok = true; std::string err; uint64_t next_coff = 0; };
     const uint32_t W = std::max<uint32_t>(opt.window_blocks, 1);
     const size_t kHead = 1 << 20;                        // room in front of each batch for the carried partial record (grown when needed)
     auto load = [&](uint64_t coff, Batch &b, size_t head) {
@@ -232,7 +246,7 @@ bool BamReader::stream(uint64_t start_voffset, const BamReadOptions &opt, const 
         }
         b.next_coff = coff;
         b.head = head;
-        b.data.resize(head + total);
+        b.data.resize_uninit(head + total);
         if (!bgzf::inflate_range(file.data(), b.blocks, 0, b.blocks.size(), b.data.data() + head, opt.threads, &b.err)) b.ok = false;
     };
     Batch batch[2];
@@ -242,6 +256,8 @@ bool BamReader::stream(uint64_t start_voffset, const BamReadOptions &opt, const 
     load(coff, batch[0], kHead);
     int cur = 0;
     std::vector<uint8_t> carry;
+    HugeVec<uint8_t> joined;                             // only when a carried record is larger than the head room
+    std::vector<RecRef> recs;
     for (;;) {
         Batch &b = batch[cur];
         if (!b.ok) { err = b.err; return false; }
@@ -249,25 +265,33 @@ bool BamReader::stream(uint64_t start_voffset, const BamReadOptions &opt, const 
         std::future<void> ahead;
         const bool more = b.next_coff < file.size();
         if (more) ahead = std::async(std::launch::async, load, b.next_coff, std::ref(batch[cur ^ 1]), kHead);
+        auto fail = [&](const std::string &m) { err = m; if (more) ahead.get(); return false; };
         // records of this batch = carried bytes + inflated bytes
         uint8_t *p = b.data.data() + b.head;
         size_t n = b.data.size() - b.head;
-        if (skip) { if (skip > n) { err = "BAM: virtual offset beyond its block"; if (more) ahead.get(); return false; } p += skip; n -= skip; skip = 0; }
+        if (skip) { if (skip > n) return fail("BAM: virtual offset beyond its block"); p += skip; n -= skip; skip = 0; }
         if (!carry.empty()) {
             if (carry.size() <= (size_t)(p - b.data.data())) { p -= carry.size(); memcpy(p, carry.data(), carry.size()); n += carry.size(); }
-            else { carry.insert(carry.end(), p, p + n); b.data.swap(carry); p = b.data.data(); n = b.data.size(); }
+            else {
+                joined.clear();
+                joined.append(carry.data(), carry.size());
+                joined.append(p, n);
+                p = joined.data(); n = joined.size();
+            }
             carry.clear();
         }
+        recs.clear();
         size_t o = 0;
-        bool stop = false;
         while (o + 4 <= n) {
             const uint32_t bs = le32(p + o);
-            if (bs < 32) { err = "BAM: record shorter than its fixed fields"; if (more) ahead.get(); return false; }
+            if (bs < 32) return fail("BAM: record shorter than its fixed fields");
+            if (bs > (1u << 30)) return fail("BAM: implausible record length");
             if (o + 4 + (size_t)bs > n) break;
-            if (!on_record(p + o + 4, bs)) { stop = true; break; }
+            recs.push_back(RecRef{p + o + 4, bs});
             o += 4 + (size_t)bs;
         }
-        if (stop || !err.empty()) { if (more) ahead.get(); return err.empty(); }
+        const size_t took = on_batch(recs.data(), recs.size());
+        if (took < recs.size() || !err.empty()) { if (more) ahead.get(); return err.empty(); }
         carry.assign(p + o, p + n);
         if (!more) break;
         ahead.get();
@@ -277,41 +301,64 @@ bool BamReader::stream(uint64_t start_voffset, const BamReadOptions &opt, const 
     return true;
 }
 
-bool BamReader::append(const uint8_t *rec, uint32_t len, const BamReadOptions &opt, BamShard &out)
+// Records -> arrays: a serial pass sizes every record (and resolves CG-tag CIGARs), then the copies run on the pool.
+bool BamReader::append(const RecRef *recs, size_t n, const BamReadOptions &opt, BamShard &out)
 {
-    const uint32_t l_name = rec[8], n_cigar = le16(rec + 12);
-    const int32_t l_seq = (int32_t)le32(rec + 16);
-    if (l_seq < 0) { err = "BAM: negative sequence length"; return false; }
-    const size_t fixed = 32 + (size_t)l_name + 4ull * n_cigar + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
-    if (fixed > len) { err = "BAM: record fields exceed the record length"; return false; }
-    const int32_t tid = (int32_t)le32(rec), pos = (int32_t)le32(rec + 4);
-    const uint8_t *cig = rec + 32 + l_name;
-    const uint8_t *seq = cig + 4ull * n_cigar;
-    out.pos.push_back(pos);
-    out.flag.push_back(le16(rec + 14));
-    out.mapq.push_back(rec[9]);
-    // long CIGAR in the CG tag behind a <l_seq>S<n>N placeholder (bam_tag2cigar)
-    const uint8_t *real = nullptr;
-    uint32_t real_n = 0;
-    if (n_cigar > 0 && tid >= 0 && pos >= 0) {
-        const uint32_t c0 = le32(cig);
-        if ((c0 & 15) == OP_S && (int32_t)(c0 >> 4) == l_seq) {
-            uint32_t cnt = 0;
-            const uint8_t *cg = find_cg(rec + fixed, rec + len, &cnt);
-            if (cg && cnt >= n_cigar && cnt < (1u << 29)) { real = cg; real_n = cnt; }
+    if (n == 0) return true;
+    struct Src { const uint8_t *cig; uint32_t n_cig; };
+    std::vector<Src> src(n);
+    const size_t r0 = out.pos.size();
+    out.cigar_off.resize(r0 + 1 + n);
+    if (opt.want_seq) out.seq_off.resize(r0 + 1 + n);
+    uint64_t cig_at = out.cigar.size(), seq_at = out.seq.size();
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *rec = recs[i].p;
+        const uint32_t len = recs[i].len;
+        const uint32_t l_name = rec[8], n_cigar = le16(rec + 12);
+        const int32_t l_seq = (int32_t)le32(rec + 16);
+        if (l_seq < 0) { err = "BAM: negative sequence length"; return false; }
+        const size_t fixed = 32 + (size_t)l_name + 4ull * n_cigar + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+        if (fixed > len) { err = "BAM: record fields exceed the record length"; return false; }
+        const uint8_t *cig = rec + 32 + l_name;
+        src[i] = Src{cig, n_cigar};
+        // long CIGAR in the CG tag behind a <l_seq>S<n>N placeholder (bam_tag2cigar)
+        if (n_cigar > 0 && (int32_t)le32(rec) >= 0 && (int32_t)le32(rec + 4) >= 0) {
+            const uint32_t c0 = le32(cig);
+            if ((c0 & 15) == OP_S && (int32_t)(c0 >> 4) == l_seq) {
+                uint32_t cnt = 0;
+                const uint8_t *cg = find_cg(rec + fixed, rec + len, &cnt);
+                if (cg && cnt >= n_cigar && cnt < (1u << 29)) src[i] = Src{cg, cnt};
+            }
         }
+        cig_at += src[i].n_cig;
+        out.cigar_off[r0 + 1 + i] = cig_at;
+        if (opt.want_seq) { seq_at += ((size_t)l_seq + 1) / 2; out.seq_off[r0 + 1 + i] = seq_at; }
     }
-    const uint8_t *src = real ? real : cig;
-    const uint32_t cnt = real ? real_n : n_cigar;
-    const size_t at = out.cigar.size();
-    out.cigar.resize(at + cnt);
-    if (cnt) memcpy(out.cigar.data() + at, src, 4ull * cnt);       // BAM is little-endian, as is the target
-    out.cigar_off.push_back(out.cigar.size());
-    if (opt.want_seq) {
-        out.seq.insert(out.seq.end(), seq, seq + ((size_t)l_seq + 1) / 2);
-        out.seq_off.push_back(out.seq.size());
-    }
-    if (opt.want_qnames) out.qnames.emplace_back((const char *)rec + 32, l_name ? strnlen((const char *)rec + 32, l_name) : 0);
+    out.pos.resize(r0 + n);
+    out.flag.resize(r0 + n);
+    out.mapq.resize(r0 + n);
+    out.cigar.resize_uninit(cig_at);
+    if (opt.want_seq) out.seq.resize_uninit(seq_at);
+    if (opt.want_qnames) out.qnames.resize(r0 + n);
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(opt.threads, 1), n / 256 + 1));
+    parallel_chunks(nt, [&](int t) {
+        const size_t a = n * (size_t)t / (size_t)nt, b = n * ((size_t)t + 1) / (size_t)nt;
+        for (size_t i = a; i < b; i++) {
+            const uint8_t *rec = recs[i].p;
+            const size_t r = r0 + i;
+            out.pos[r] = (int32_t)le32(rec + 4);
+            out.mapq[r] = rec[9];
+            out.flag[r] = le16(rec + 14);
+            if (src[i].n_cig) memcpy(out.cigar.data() + out.cigar_off[r], src[i].cig, 4ull * src[i].n_cig);   // BAM is little-endian, as is the target
+            const uint32_t l_name = rec[8];
+            if (opt.want_seq) {
+                const uint8_t *seq = rec + 32 + l_name + 4ull * le16(rec + 12);
+                const size_t nb = (size_t)(out.seq_off[r + 1] - out.seq_off[r]);
+                if (nb) memcpy(out.seq.data() + out.seq_off[r], seq, nb);
+            }
+            if (opt.want_qnames) out.qnames[r].assign((const char *)rec + 32, l_name ? strnlen((const char *)rec + 32, l_name) : 0);
+        }
+    });
     return true;
 }
 
@@ -324,12 +371,19 @@ bool BamReader::readContig(const std::string &chr, const BamReadOptions &opt, Ba
     out.clear();
     out.tid = tid; out.name = chr; out.target_len = hdr.lens[tid];
     if ((size_t)tid >= index->refs.size() || !index->refs[tid].any) return true;
+    const Index::Ref &ref = index->refs[tid];
+    // size the big arrays once: the contig's compressed span bounds its records (BGZF rarely expands; CIGAR words dominate)
+    const uint64_t span = ((ref.max_end >> 16) - (ref.min_beg >> 16)) + bgzf::kMaxBlock;
+    out.cigar.reserve((size_t)(span * 4 / 4));            // ~4x compression of CIGAR words is typical; growth is by mremap anyway
     const int64_t end = hdr.lens[tid];
-    return stream(index->refs[tid].min_beg, opt, [&](const uint8_t *rec, uint32_t len) {
-        const int32_t rtid = (int32_t)le32(rec), pos = (int32_t)le32(rec + 4);
-        if (rtid != tid) return rtid >= 0 && rtid < tid;           // earlier contig: keep going; later one or unplaced: done
-        if (pos >= end) return false;                               // iterator finishes at the first record past the region
-        return append(rec, len, opt, out);
+    return stream(ref.min_beg, opt, [&](const RecRef *recs, size_t n) -> size_t {
+        // the contig's records are one run in a sorted file: skip an earlier contig's tail, stop at a later one / unplaced / past the end
+        size_t a = 0;
+        while (a < n && (int32_t)le32(recs[a].p) >= 0 && (int32_t)le32(recs[a].p) < tid) a++;
+        size_t b = a;
+        while (b < n && (int32_t)le32(recs[b].p) == tid && (int32_t)le32(recs[b].p + 4) < end) b++;
+        if (!append(recs + a, b - a, opt, out)) return 0;
+        return b == n ? n : b;                            // anything left over ends the iteration
     }) && err.empty();
 }
 
@@ -344,14 +398,23 @@ bool BamReader::readAll(const BamReadOptions &opt, const std::function<void(BamS
         cur = BamShard();
         cur.clear();
     };
-    const bool ok = stream(first_record_voffset, opt, [&](const uint8_t *rec, uint32_t len) {
-        const int32_t rtid = (int32_t)le32(rec);
-        if (rtid < 0 || (size_t)rtid >= hdr.names.size()) { unplaced++; return true; }
-        if (rtid != cur.tid) {
-            flush();
-            cur.tid = rtid; cur.name = hdr.names[rtid]; cur.target_len = hdr.lens[rtid];
+    const bool ok = stream(first_record_voffset, opt, [&](const RecRef *recs, size_t n) -> size_t {
+        size_t i = 0;
+        while (i < n) {
+            const int32_t rtid = (int32_t)le32(recs[i].p);
+            size_t j = i + 1;
+            while (j < n && (int32_t)le32(recs[j].p) == rtid) j++;
+            if (rtid < 0 || (size_t)rtid >= hdr.names.size()) unplaced += j - i;
+            else {
+                if (rtid != cur.tid) {
+                    flush();
+                    cur.tid = rtid; cur.name = hdr.names[rtid]; cur.target_len = hdr.lens[rtid];
+                }
+                if (!append(recs + i, j - i, opt, cur)) return 0;
+            }
+            i = j;
         }
-        return append(rec, len, opt, cur);
+        return n;
     }) && err.empty();
     if (ok) flush();
     if (n_unplaced) *n_unplaced = unplaced;

@@ -15,6 +15,7 @@
 
 #include "../../../include/csvgpu.h"
 #include "bgzf.h"
+#include "hugevec.h"
 
 struct BamHeader {
     std::string text;
@@ -32,9 +33,9 @@ struct BamShard {
     std::vector<uint16_t> flag;
     std::vector<uint8_t>  mapq;
     std::vector<uint64_t> cigar_off;                  // [n + 1]
-    std::vector<uint32_t> cigar;                      // BAM words (len << 4 | op), CG-tag CIGARs already restored
+    HugeVec<uint32_t> cigar;                          // BAM words (len << 4 | op), CG-tag CIGARs already restored
     std::vector<uint64_t> seq_off;                    // [n + 1] byte offsets into seq (want_seq)
-    std::vector<uint8_t>  seq;                        // 4-bit packed, high nibble first, as bam_get_seq
+    HugeVec<uint8_t> seq;                             // 4-bit packed, high nibble first, as bam_get_seq
     std::vector<std::string> qnames;                  // (want_qnames)
     uint64_t n_reads() const { return pos.size(); }
     csv_reads view() const;                           // host pointers into this shard (tid = nullptr)
@@ -72,8 +73,10 @@ public:
 
 private:
     struct Index;
-    bool stream(uint64_t start_voffset, const BamReadOptions &opt, const std::function<bool(const uint8_t *, uint32_t)> &on_record);
-    bool append(const uint8_t *rec, uint32_t len, const BamReadOptions &opt, BamShard &out);
+    struct RecRef { const uint8_t *p; uint32_t len; };        // one record behind its block_size field
+    // Hands the records of each inflated batch to on_batch, which returns how many of them it consumed: fewer than n ends the stream.
+    bool stream(uint64_t start_voffset, const BamReadOptions &opt, const std::function<size_t(const RecRef *, size_t)> &on_batch);
+    bool append(const RecRef *recs, size_t n, const BamReadOptions &opt, BamShard &out);
     bgzf::MappedFile file;
     BamHeader hdr;
     uint64_t first_record_voffset = 0;

@@ -59,26 +59,41 @@ bool scan_blocks(const uint8_t *file, size_t size, uint64_t from, std::vector<Bl
     return true;
 }
 
+namespace {
+// one inflate state per worker, reset per block (inflateInit2 allocates ~40 KiB; doing that per 64 KiB block is measurable
+// and serialises threads in the allocator)
+struct Inflater {
+    z_stream zs;
+    bool ready = false;
+    Inflater() { memset(&zs, 0, sizeof zs); }
+    ~Inflater() { if (ready) inflateEnd(&zs); }
+    bool run(const uint8_t *file, const Block &b, uint8_t *dst, std::string *err)
+    {
+        if (b.isize == 0) return true;
+        if (!ready) {
+            if (inflateInit2(&zs, -15) != Z_OK) { set(err, "BGZF: inflateInit2 failed"); return false; }
+            ready = true;
+        } else if (inflateReset(&zs) != Z_OK) { set(err, "BGZF: inflateReset failed"); return false; }
+        const uint8_t *src = file + b.coffset;
+        zs.next_in = const_cast<Bytef *>(src + b.data_off);
+        zs.avail_in = b.csize - b.data_off - 8;
+        zs.next_out = dst;
+        zs.avail_out = b.isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs.total_out != b.isize) { set(err, "BGZF: inflate failed at offset " + std::to_string(b.coffset)); return false; }
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.isize) != le32(src + b.csize - 8)) {
+            set(err, "BGZF: CRC mismatch at offset " + std::to_string(b.coffset));
+            return false;
+        }
+        return true;
+    }
+};
+}  // namespace
+
 bool inflate_block(const uint8_t *file, const Block &b, uint8_t *dst, std::string *err)
 {
-    if (b.isize == 0) return true;
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { set(err, "BGZF: inflateInit2 failed"); return false; }
-    const uint8_t *src = file + b.coffset;
-    zs.next_in = const_cast<Bytef *>(src + b.data_off);
-    zs.avail_in = b.csize - b.data_off - 8;
-    zs.next_out = dst;
-    zs.avail_out = b.isize;
-    const int rc = inflate(&zs, Z_FINISH);
-    const bool ok = rc == Z_STREAM_END && zs.total_out == b.isize;
-    inflateEnd(&zs);
-    if (!ok) { set(err, "BGZF: inflate failed at offset " + std::to_string(b.coffset)); return false; }
-    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.isize) != le32(src + b.csize - 8)) {
-        set(err, "BGZF: CRC mismatch at offset " + std::to_string(b.coffset));
-        return false;
-    }
-    return true;
+    Inflater z;
+    return z.run(file, b, dst, err);
 }
 
 bool inflate_range(const uint8_t *file, const std::vector<Block> &blocks, size_t first, size_t last, uint8_t *dst, int threads, std::string *err)
@@ -93,11 +108,12 @@ bool inflate_range(const uint8_t *file, const std::vector<Block> &blocks, size_t
     std::string first_err;
     std::atomic_flag err_lock = ATOMIC_FLAG_INIT;
     auto work = [&] {
+        Inflater z;
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= last || failed.load(std::memory_order_relaxed)) return;
             std::string e;
-            if (!inflate_block(file, blocks[i], dst + uoff[i - first], &e)) {
+            if (!z.run(file, blocks[i], dst + uoff[i - first], &e)) {
                 failed = true;
                 if (!err_lock.test_and_set()) first_err = e;
                 return;

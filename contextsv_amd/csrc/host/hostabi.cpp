@@ -562,7 +562,7 @@ struct csvhost_bam_stats { uint64_t n_contigs, n_reads, n_cigar, bam_bytes; doub
 // SVCaller::runBam: chrs = '\n'-separated contig names or null (all). SNPs: none (every window gets the dummy observation).
 // Calls come back grouped by contig in header order, with their contig index in out_tid.
 int csvhost_run_bam(csv_ctx *ctx, const char *bam_path, const char *chrs, int threads, const csv_hmm *hmm, double eps, double min_pts_pct,
-                    int sample_size, uint32_t min_cnv, int split_svs, const csvhost_fasta *fasta, const char *vcf_dir, const char *gap_path,
+                    int sample_size, uint32_t min_cnv, int passes /* bit 0: split-read pass, bit 1: CIGAR copy-number pass */, const csvhost_fasta *fasta, const char *vcf_dir, const char *gap_path,
                     const char *file_date, csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out, csvhost_bam_stats *stats)
 {
     GUARD({
@@ -573,7 +573,7 @@ int csvhost_run_bam(csv_ctx *ctx, const char *bam_path, const char *chrs, int th
             p = e ? e + 1 : p + strlen(p);
         }
         RunParams P; P.dbscan_epsilon = eps; P.dbscan_min_pts_pct = min_pts_pct; P.sample_size = sample_size; P.min_cnv_length = min_cnv;
-        P.split_svs = split_svs != 0;
+        P.split_svs = (passes & 1) != 0; P.cigar_cn = (passes & 2) != 0;
         if (fasta && vcf_dir) {
             P.ref_genome = fasta_genome(fasta);
             P.vcf.output_dir = vcf_dir; P.vcf.assembly_gaps = gap_path ? gap_path : ""; P.vcf.file_date = file_date ? file_date : "";

@@ -487,7 +487,7 @@ def write_bam(path: str, ref_names, ref_lens, tid, reads: Reads, qnames, seq_off
                                     p(mapq), p(coff), p(cig), "\n".join(qnames).encode(), p(so), p(sq), p(ls), level, threads))
 
 
-def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True,
+def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True, cigar_cn=True,
             genome: ReferenceGenome | None = None, vcf_dir=None, gap_path=None, file_date=None, capacity: int = 1 << 20):
     """SVCaller::runBam: the whole run fed from a coordinate-sorted, indexed BAM. -> (calls, contig index per call, stats dict)."""
     out = np.zeros(capacity, CALL_DTYPE)
@@ -495,7 +495,7 @@ def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0
     n = C.c_uint64(0)
     st = bam_stats()
     _check(load().csvhost_run_bam(ctx.h, os.fsencode(bam_path), "\n".join(chromosomes).encode() if chromosomes else None, threads, C.byref(hmm), eps,
-                                  min_pts_pct, sample_size, min_cnv, int(split_svs), genome.h if genome is not None and vcf_dir else None,
+                                  min_pts_pct, sample_size, min_cnv, int(split_svs) | (int(cigar_cn) << 1), genome.h if genome is not None and vcf_dir else None,
                                   os.fsencode(vcf_dir) if vcf_dir else None, os.fsencode(gap_path) if gap_path else None,
                                   file_date.encode() if file_date else None, out.ctypes.data, tid.ctypes.data, capacity, C.byref(n), C.byref(st)))
     if n.value > capacity:
