@@ -16,6 +16,7 @@
 #include "fasta_query.h"
 #include "vcf_writer.h"
 #include "bam_io.h"
+#include "snp_io.h"
 #include <fstream>
 #include <algorithm>
 #include <vector>
@@ -563,7 +564,8 @@ struct csvhost_bam_stats { uint64_t n_contigs, n_reads, n_cigar, bam_bytes; doub
 // Calls come back grouped by contig in header order, with their contig index in out_tid.
 int csvhost_run_bam(csv_ctx *ctx, const char *bam_path, const char *chrs, int threads, const csv_hmm *hmm, double eps, double min_pts_pct,
                     int sample_size, uint32_t min_cnv, int passes /* bit 0: split-read pass, bit 1: CIGAR copy-number pass */, const csvhost_fasta *fasta, const char *vcf_dir, const char *gap_path,
-                    const char *file_date, csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out, csvhost_bam_stats *stats)
+                    const char *file_date, csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out, csvhost_bam_stats *stats,
+                    const char *snp_vcf, const char *pfb_table, const char *ethnicity)
 {
     GUARD({
         std::vector<std::string> list;
@@ -574,6 +576,7 @@ int csvhost_run_bam(csv_ctx *ctx, const char *bam_path, const char *chrs, int th
         }
         RunParams P; P.dbscan_epsilon = eps; P.dbscan_min_pts_pct = min_pts_pct; P.sample_size = sample_size; P.min_cnv_length = min_cnv;
         P.split_svs = (passes & 1) != 0; P.cigar_cn = (passes & 2) != 0;
+        P.snp_vcf = snp_vcf ? snp_vcf : ""; P.pfb_table = pfb_table ? pfb_table : ""; P.ethnicity = ethnicity ? ethnicity : "";
         if (fasta && vcf_dir) {
             P.ref_genome = fasta_genome(fasta);
             P.vcf.output_dir = vcf_dir; P.vcf.assembly_gaps = gap_path ? gap_path : ""; P.vcf.file_date = file_date ? file_date : "";
@@ -602,6 +605,52 @@ int csvhost_run_bam(csv_ctx *ctx, const char *bam_path, const char *chrs, int th
         if (stats) { stats->n_contigs = bs.n_contigs; stats->n_reads = bs.n_reads; stats->n_cigar = bs.n_cigar; stats->bam_bytes = bs.bam_bytes;
                      stats->ms_decode = bs.ms_decode; stats->ms_total = bs.ms_total; }
     })
+}
+
+// ---- SNP / population-frequency VCF ingestion (snp_io) ------------------------------------------------------
+struct csvhost_snp { SNPFile f; };
+
+csvhost_snp *csvhost_snp_open(const char *snp_vcf, int threads)
+{
+    csvhost_snp *h = new csvhost_snp();
+    std::string e;
+    if (!h->f.load(snp_vcf ? snp_vcf : "", threads, &e)) { g_err = e; delete h; return nullptr; }
+    return h;
+}
+void csvhost_snp_free(csvhost_snp *h) { delete h; }
+uint64_t csvhost_snp_kept(const csvhost_snp *h) { return h->f.records_kept(); }
+
+// readSNPAlleleFrequencies for one region from the loaded tables. Returns the number of positions (file order), -1 when cap is too
+// small. baf_out[i] = map value at pos_out[i]; at most one population frequency (has_pfb, pfb_pos, pfb_val).
+int64_t csvhost_snp_query(csvhost_snp *h, const char *chr, const char *pfb_vcf, const char *ethnicity, uint32_t start_pos, uint32_t end_pos,
+                          uint32_t *pos_out, double *baf_out, uint64_t cap, int *has_pfb, uint32_t *pfb_pos, double *pfb_val, int threads)
+{
+    const SNPFileTable &t = h->f.table(chr, pfb_vcf ? pfb_vcf : "", ethnicity ? ethnicity : "", threads);
+    std::vector<uint32_t> pos;
+    std::unordered_map<uint32_t, double> baf, pfb;
+    t.query(start_pos, end_pos, pos, baf, pfb);
+    *has_pfb = 0;
+    if (pos.size() > cap) return -1;
+    for (size_t i = 0; i < pos.size(); i++) { pos_out[i] = pos[i]; baf_out[i] = baf[pos[i]]; }
+    if (!pfb.empty()) { *has_pfb = (int)pfb.size(); *pfb_pos = pfb.begin()->first; *pfb_val = pfb.begin()->second; }
+    return (int64_t)pos.size();
+}
+
+// the --pfb table: path for `chr` copied to buf (empty when absent); -1 when the table cannot be loaded
+int64_t csvhost_pfb_path(const char *table_path, const char *chr, char *buf, uint64_t cap)
+{
+    AlleleFreqFiles a;
+    std::string e;
+    if (!a.load(table_path, &e)) { g_err = e; return -1; }
+    const std::string p = a.get(chr);
+    if (buf && cap) { memcpy(buf, p.data(), (size_t)std::min<uint64_t>(cap, p.size())); }
+    return (int64_t)p.size();
+}
+int64_t csvhost_gnomad_contig(const char *chr, const char *pfb_path, char *buf, uint64_t cap)
+{
+    const std::string g = gnomadContigName(chr, pfb_path);
+    if (buf && cap) memcpy(buf, g.data(), (size_t)std::min<uint64_t>(cap, g.size()));
+    return (int64_t)g.size();
 }
 
 // ---- HMM file + Viterbi seam ------------------------------------------------------------------

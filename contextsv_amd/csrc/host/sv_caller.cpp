@@ -298,6 +298,7 @@ void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
 #include <future>
 
 #include "bam_io.h"
+#include "snp_io.h"
 
 namespace {
 // Contigs decoded one ahead: while run() has contig i on the device, the inflate pool works on contig i + 1.
@@ -310,6 +311,9 @@ struct BamSource : ContigSource {
     SeqStore seq;
     size_t i = 0;
     BamRunStats st;
+    SNPFile *snp_file = nullptr;                                  // loaded SNP VCF, or nullptr
+    const AlleleFreqFiles *af_files = nullptr;
+    std::string ethnicity;
 
     void launch(size_t k) { pending = std::async(std::launch::async, [this, k] { return reader.readContig(chrs[k], opt, ahead); }); }
 
@@ -331,6 +335,7 @@ struct BamSource : ContigSource {
         out.seq = opt.want_seq ? &seq : nullptr;
         out.depth_len = cur.target_len + 1;                       // cnv_caller.cpp:482
         out.qnames = opt.want_qnames ? &cur.qnames : nullptr;
+        if (snp_file) out.snps = &snp_file->table(cur.name, af_files ? af_files->get(cur.name) : std::string(), ethnicity, opt.threads);
         st.n_contigs++; st.n_reads += cur.n_reads(); st.n_cigar += cur.cigar.size();
         i++;
         return true;
@@ -355,6 +360,17 @@ void SVCaller::runBam(const std::string &bam_path, const std::vector<std::string
         }
     }
     src.opt.threads = std::max(1, threads);
+    SNPFile snp_file;
+    AlleleFreqFiles af_files;
+    if (!P.snp_vcf.empty()) {
+        std::string e;
+        if (!af_files.load(P.pfb_table, &e)) throw std::runtime_error(e);          // the reference exits (input_data.cpp:221-225, :278-283)
+        if (snp_file.load(P.snp_vcf, src.opt.threads, &e)) {
+            src.snp_file = &snp_file; src.af_files = &af_files; src.ethnicity = P.ethnicity;
+        } else {
+            printError(e);                                                         // as there: every region then has no SNPs (cnv_caller.cpp:586-591)
+        }
+    }
     src.opt.want_seq = true;                                      // 50-bp insertion ALT strings (sv_caller.cpp:589-600)
     src.opt.want_qnames = P.split_svs;
     run(src, hmm, P, whole_genome_sv_calls);

@@ -56,6 +56,9 @@ struct RunParams {
     int sample_size = 20;                   // --sample-size
     uint32_t min_cnv_length = 2000;         // --min-cnv
     bool cigar_svs = true, cigar_cn = true, split_svs = true, merge_split_svs = true, merge_final_svs = true;   // sv_caller.cpp:749-753
+    std::string snp_vcf;                    // --snp: the sample's SNP VCF (runBam; "" = no SNPs, every window gets the dummy observation)
+    std::string pfb_table;                  // --pfb: "<chr>=<gnomAD VCF>" table
+    std::string ethnicity;                  // --eth: AF_<eth> instead of AF
     const ReferenceGenome *ref_genome = nullptr;   // with vcf.output_dir set: write <output_dir>/output.vcf at the end (sv_caller.cpp:943-945)
     VCFOptions vcf;
 };

@@ -93,7 +93,20 @@ def load() -> C.CDLL:
                                       C.c_int, C.c_int]
     lib.csvhost_synth_write_bam.argtypes = [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     lib.csvhost_run_bam.argtypes = [_P, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_lib.csv_hmm), C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int,
-                                    _P, C.c_char_p, C.c_char_p, C.c_char_p, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(bam_stats)]
+                                    _P, C.c_char_p, C.c_char_p, C.c_char_p, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(bam_stats),
+                                    C.c_char_p, C.c_char_p, C.c_char_p]
+    lib.csvhost_snp_open.restype = _P
+    lib.csvhost_snp_open.argtypes = [C.c_char_p, C.c_int]
+    lib.csvhost_snp_free.argtypes = [_P]
+    lib.csvhost_snp_kept.restype = C.c_uint64
+    lib.csvhost_snp_kept.argtypes = [_P]
+    lib.csvhost_snp_query.restype = C.c_int64
+    lib.csvhost_snp_query.argtypes = [_P, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, _P, _P, C.c_uint64, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.c_int]
+    lib.csvhost_pfb_path.restype = C.c_int64
+    lib.csvhost_pfb_path.argtypes = [C.c_char_p, C.c_char_p, _P, C.c_uint64]
+    lib.csvhost_gnomad_contig.restype = C.c_int64
+    lib.csvhost_gnomad_contig.argtypes = [C.c_char_p, C.c_char_p, _P, C.c_uint64]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -488,7 +501,8 @@ def write_bam(path: str, ref_names, ref_lens, tid, reads: Reads, qnames, seq_off
 
 
 def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True, cigar_cn=True,
-            genome: ReferenceGenome | None = None, vcf_dir=None, gap_path=None, file_date=None, capacity: int = 1 << 20):
+            genome: ReferenceGenome | None = None, vcf_dir=None, gap_path=None, file_date=None, capacity: int = 1 << 20,
+            snp_vcf=None, pfb_table=None, ethnicity=""):
     """SVCaller::runBam: the whole run fed from a coordinate-sorted, indexed BAM. -> (calls, contig index per call, stats dict)."""
     out = np.zeros(capacity, CALL_DTYPE)
     tid = np.zeros(capacity, np.int32)
@@ -497,7 +511,54 @@ def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0
     _check(load().csvhost_run_bam(ctx.h, os.fsencode(bam_path), "\n".join(chromosomes).encode() if chromosomes else None, threads, C.byref(hmm), eps,
                                   min_pts_pct, sample_size, min_cnv, int(split_svs) | (int(cigar_cn) << 1), genome.h if genome is not None and vcf_dir else None,
                                   os.fsencode(vcf_dir) if vcf_dir else None, os.fsencode(gap_path) if gap_path else None,
-                                  file_date.encode() if file_date else None, out.ctypes.data, tid.ctypes.data, capacity, C.byref(n), C.byref(st)))
+                                  file_date.encode() if file_date else None, out.ctypes.data, tid.ctypes.data, capacity, C.byref(n), C.byref(st),
+                                  os.fsencode(snp_vcf) if snp_vcf else None, os.fsencode(pfb_table) if pfb_table else None, ethnicity.encode()))
     if n.value > capacity:
         raise RuntimeError("run_bam: capacity too small")
     return out[: n.value].copy(), tid[: n.value].copy(), {f: getattr(st, f) for f, _ in bam_stats._fields_}
+
+
+class SNPFile:
+    """The sample's SNP VCF (.vcf or bgzipped + indexed .vcf.gz) parsed once with the reference's filters; query() gives what
+    readSNPAlleleFrequencies returns for a region: (positions in file order, BAF at those positions, (pfb_pos, pfb) or None)."""
+
+    def __init__(self, snp_vcf: str, threads: int = 4):
+        self.h = load().csvhost_snp_open(os.fsencode(snp_vcf), threads)
+        if not self.h:
+            raise RuntimeError((load().csvhost_last_error() or b"cannot load SNP VCF").decode())
+
+    def close(self):
+        if self.h:
+            load().csvhost_snp_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def records_kept(self) -> int:
+        return int(load().csvhost_snp_kept(self.h))
+
+    def query(self, chr: str, start: int, end: int, pfb_vcf: str | None = None, ethnicity: str = "", threads: int = 4, cap: int = 1 << 20):
+        pos, baf = np.zeros(cap, np.uint32), np.zeros(cap, np.float64)
+        has, pp, pv = C.c_int(0), C.c_uint32(0), C.c_double(0)
+        n = load().csvhost_snp_query(self.h, chr.encode(), os.fsencode(pfb_vcf) if pfb_vcf else None, ethnicity.encode(), start, end,
+                                     pos.ctypes.data, baf.ctypes.data, cap, C.byref(has), C.byref(pp), C.byref(pv), threads)
+        if n < 0:
+            raise RuntimeError("SNP query: capacity too small")
+        return pos[:n].copy(), baf[:n].copy(), ((pp.value, pv.value) if has.value else None)
+
+
+def pfb_path(table_path: str, chr: str) -> str:
+    """InputData::getAlleleFreqFilepath over a --pfb table file."""
+    buf = C.create_string_buffer(4096)
+    n = load().csvhost_pfb_path(os.fsencode(table_path), chr.encode(), buf, 4096)
+    if n < 0:
+        raise RuntimeError((load().csvhost_last_error() or b"").decode())
+    return buf.raw[:n].decode()
+
+
+def gnomad_contig(chr: str, pfb_path_: str) -> str:
+    buf = C.create_string_buffer(4096)
+    n = load().csvhost_gnomad_contig(chr.encode(), pfb_path_.encode(), buf, 4096)
+    return buf.raw[:n].decode()

@@ -60,6 +60,18 @@ class Oracle:
         lib.orc_save_vcf.restype = C.c_int
         lib.orc_save_vcf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, P, P, P, P, P, P, P]
 
+    def read_snp_af(self, snp_txt, pfb_txt, chr, chr_gnomad, start, end, af_key, cap=1 << 20):
+        """readSNPAlleleFrequencies restated for one region over plain-text VCFs -> (pos, baf, (pfb_pos, pfb) | None)."""
+        self.lib.orc_read_snp_af.restype = C.c_int64
+        self.lib.orc_read_snp_af.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, P, P, C.c_uint64,
+                                             C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        pos, baf = np.zeros(cap, np.uint32), np.zeros(cap, np.float64)
+        has, pp, pv = C.c_int(0), C.c_uint32(0), C.c_double(0)
+        n = self.lib.orc_read_snp_af(snp_txt.encode(), pfb_txt.encode() if pfb_txt else None, chr.encode(), chr_gnomad.encode(), start, end,
+                                     af_key.encode(), pos.ctypes.data, baf.ctypes.data, cap, C.byref(has), C.byref(pp), C.byref(pv))
+        assert n >= 0, n
+        return pos[:n].copy(), baf[:n].copy(), ((pp.value, pv.value) if has.value else None)
+
     def fasta_query(self, fasta, chr, a, b):
         """ReferenceGenome::query restated; None for an unknown contig."""
         n = self.lib.orc_fasta_query(fasta.encode(), chr.encode(), a, b, None, 0)

@@ -13,8 +13,19 @@ pytestmark = pytest.mark.gpu
 
 def test_run_from_bam_equals_run_from_arrays(ctx, tmp_path):
     contigs = _build(7)
-    for c in contigs:                                      # runBam has no SNP input yet (§8f-3): compare without SNPs
-        c["snps"] = {"pos": np.zeros(0, np.uint32), "baf": np.zeros(0), "pfb": np.zeros(0), "has_pfb": np.zeros(0, np.uint8)}
+    # SNPs as a VCF for runBam and as the same numbers in arrays for run: BAF = AD[1] / (AD[0] + AD[1]); no population file
+    rng = np.random.default_rng(3)
+    vcf = ["##fileformat=VCFv4.2", '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">',
+           '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="a">', "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS"]
+    for t, c in enumerate(contigs):
+        pos = c["snps"]["pos"]
+        dp = rng.integers(20, 60, len(pos))
+        a1 = np.where(rng.random(len(pos)) < 0.6, dp // 2 + rng.integers(-3, 4, len(pos)), rng.choice([0, 1], len(pos)) * dp)
+        c["snps"] = {"pos": pos, "baf": a1 / dp, "pfb": np.zeros(len(pos)), "has_pfb": np.zeros(len(pos), np.uint8)}
+        vcf += ["contig%d\t%d\t.\tA\tG\t60\tPASS\t.\tGT:DP:AD\t0/1:%d:%d,%d" % (t, p, d, d - a, a) for p, d, a in zip(pos, dp, a1)]
+        vcf.append("contig%d\t%d\t.\tA\tGT\t60\tPASS\t.\tGT:DP:AD\t0/1:30:15,15" % (t, int(pos[-1]) + 5))      # an indel: ignored
+    snp_vcf = str(tmp_path / "snps.vcf")
+    open(snp_vcf, "w").write("\n".join(vcf) + "\n")
     hmm = make_hmm(**WGS_HMM)
     fasta = str(tmp_path / "genome.fa")
     _write_genome(fasta, len(contigs), np.random.default_rng(1))
@@ -32,7 +43,7 @@ def test_run_from_bam_equals_run_from_arrays(ctx, tmp_path):
     bam = str(tmp_path / "reads.bam")
     host.write_bam(bam, ["contig%d" % t for t in range(len(contigs))], [CONTIG_LEN] * len(contigs), tid, reads, qnames, level=1, threads=8)
 
-    got, got_tid, st = host.run_bam(ctx, bam, hmm, threads=8, genome=genome, vcf_dir=str(tmp_path / "b"), file_date="20250926")
+    got, got_tid, st = host.run_bam(ctx, bam, hmm, threads=8, genome=genome, vcf_dir=str(tmp_path / "b"), file_date="20250926", snp_vcf=snp_vcf)
     assert st["n_contigs"] == len(contigs) and st["n_reads"] == reads.n_reads and st["n_cigar"] == reads.n_cigar
     assert len(got) == len(want) > 20
     assert np.array_equal(got_tid, want_tid)
@@ -42,7 +53,7 @@ def test_run_from_bam_equals_run_from_arrays(ctx, tmp_path):
     assert a == b and len(a) > 40
 
     # --chr: one contig through the index gives that contig's CIGAR calls; split-read evidence needs the other contigs' records
-    one, one_tid, st1 = host.run_bam(ctx, bam, hmm, chromosomes=["contig1"], threads=4, split_svs=False)
+    one, one_tid, st1 = host.run_bam(ctx, bam, hmm, chromosomes=["contig1"], threads=4, split_svs=False, snp_vcf=snp_vcf)
     ref1, _ = host.run(ctx, contigs[1:2], hmm)      # contig named contig0 there; positions and types are what matter
     assert st1["n_contigs"] == 1 and (one_tid == 1).all()
     cig_only = ref1[(ref1["aln_flags"] & 0b111) != 0]
