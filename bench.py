@@ -131,7 +131,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # per-kernel device time from HIP events recorded on the kernels' own stream, inside the timed region
-        kern = {k: (ms / n if n else 0.0) for k, (ms, n) in timing.items()}
+        kern = {k: ms / args.steps for k, (ms, n) in timing.items()}        # per step: a group may span several timer scopes (ordering: pre-pass + sort)
         # dbscan group = two fits (DEL + INS) per step in one timer scope; scan/depth/sort one scope per step
         alg_bytes = {
             "cigar_scan": 4.0 * reads.n_cigar + 23.0 * reads.n_reads + 16.0 * st.n_signatures,

@@ -77,7 +77,7 @@ struct ScanCounters {
     unsigned long long depth_sum;
     unsigned int       depth_nonzero;
     unsigned int       max_start;    // 0xffffffff if a signature start exceeded scan_start_limit(depth_len), else 0
-    unsigned int       max_len;      // unused
+    unsigned int       max_len;      // largest bucket of the ordering pass's most-significant-digit split (bk_prep_kernel)
     unsigned int       unsorted;     // != 0 if pos[] is not non-decreasing
     int                min_pts;      // written by the min_pts kernel
     int                pad;
@@ -134,6 +134,11 @@ size_t radix_sort_tmp_bytes(uint64_t n);
 // result is in keys_out/vals_out, 0 when it is in keys_in/vals_in (even number of passes).
 int  launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_out, uint32_t *vals_out,
                            uint64_t n, int key_bits, void *tmp);
+// bucket ordering: BK_N most-significant-digit buckets + one wave ranking each bucket; see sort.hip
+constexpr uint32_t BK_BITS = 14, BK_N = 1u << BK_BITS, BK_LOCAL_MAX = 2048;
+void launch_bucket_hist(hipStream_t s, const csv_sig *sig, ScanCounters *cnt, uint64_t cap, int type_pos, int shift, uint32_t *hist, uint32_t *cur);
+void launch_bucket_sort(hipStream_t s, const csv_sig *sig_raw, uint64_t n, int type_pos, int shift, const uint32_t *off, uint32_t *cur,
+                        csv_sig *tmp, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out);
 void launch_sig_make_keys(hipStream_t s, const csv_sig *sig, uint64_t n, int len_bits, int type_bit_pos,
                           uint64_t *keys, uint32_t *vals);
 void launch_sig_fix_ties_gather(hipStream_t s, const csv_sig *sig_raw, const uint64_t *keys, const uint32_t *vals,

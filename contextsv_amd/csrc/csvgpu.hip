@@ -92,11 +92,16 @@ struct DevReads {
     ScanCounters *cnt;
 };
 
+// device scalars + the ordering pass's bucket tables, zeroed together before every scan
+static constexpr size_t kCntBytes = 256 + 2 * (size_t)BK_N * 4;
+static inline uint32_t *bucket_off(ScanCounters *cnt) { return (uint32_t *)((char *)cnt + 256); }
+static inline uint32_t *bucket_cur(ScanCounters *cnt) { return bucket_off(cnt) + BK_N; }
+
 static size_t reads_bytes(const csv_reads *r)
 {
     const uint64_t n = r->n_reads, m = r->n_cigar;
     return align_up(n * 4, 256) + align_up(n * 2, 256) + align_up(n, 256) + align_up((n + 1) * 8, 256) + align_up(m * 4 + 16, 256) +
-           3 * align_up(n * 4, 256) + align_up(ckpt_bytes(m), 256) + 512;
+           3 * align_up(n * 4, 256) + align_up(ckpt_bytes(m), 256) + align_up(kCntBytes, 256) + 512;
 }
 
 // copy a host shard into the arena; returns device views
@@ -112,7 +117,7 @@ static int stage_reads(csv_ctx *ctx, const csv_reads *r, DevReads &o)
     o.ref_end = (int32_t *)arena_alloc(a, n * 4);
     o.q_start = (int32_t *)arena_alloc(a, n * 4);
     o.q_end = (int32_t *)arena_alloc(a, n * 4);
-    o.cnt = (ScanCounters *)arena_alloc(a, sizeof(ScanCounters));
+    o.cnt = (ScanCounters *)arena_alloc(a, kCntBytes);
     o.ckpt = (uint32_t *)arena_alloc(a, ckpt_bytes(m));
     if (!o.ckpt || !pos || !flag || !mapq || !coff || !cig || !o.ref_end || !o.q_start || !o.q_end || !o.cnt) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     hipStream_t s = ctx->stream;
@@ -123,7 +128,7 @@ static int stage_reads(csv_ctx *ctx, const csv_reads *r, DevReads &o)
     }
     CSV_HIP(ctx, hipMemcpyAsync(coff, r->cigar_off, (n + 1) * 8, hipMemcpyHostToDevice, s));
     if (m) CSV_HIP(ctx, hipMemcpyAsync(cig, r->cigar, m * 4, hipMemcpyHostToDevice, s));
-    CSV_HIP(ctx, hipMemsetAsync(o.cnt, 0, sizeof(ScanCounters), s));
+    CSV_HIP(ctx, hipMemsetAsync(o.cnt, 0, kCntBytes, s));
     o.d = *r;
     o.d.pos = pos; o.d.flag = flag; o.d.mapq = mapq; o.d.tid = nullptr; o.d.cigar_off = coff; o.d.cigar = cig;
     return CSV_OK;
@@ -154,6 +159,7 @@ struct SortWs {
     uint64_t *k0, *k1;
     uint32_t *v0, *v1;
     void *tmp;
+    csv_sig *sig_tmp;        // bucketed copy of the signatures (bucket ordering); aliases the radix key arrays, which that path does not use
 };
 static size_t sortws_bytes(uint64_t n) { return 2 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + radix_sort_tmp_bytes(n) + 256; }
 static bool sortws_carve(Arena &a, uint64_t n, SortWs &w)
@@ -161,20 +167,45 @@ static bool sortws_carve(Arena &a, uint64_t n, SortWs &w)
     w.k0 = (uint64_t *)arena_alloc(a, n * 8); w.k1 = (uint64_t *)arena_alloc(a, n * 8);
     w.v0 = (uint32_t *)arena_alloc(a, n * 4); w.v1 = (uint32_t *)arena_alloc(a, n * 4);
     w.tmp = arena_alloc(a, radix_sort_tmp_bytes(n));
-    return w.k0 && w.k1 && w.v0 && w.v1 && w.tmp;
+    w.sig_tmp = (csv_sig *)w.k0;                         // k0 and k1 are carved back to back: 2 x align_up(8n, 256) >= 16n bytes
+    return w.k0 && w.k1 && w.v0 && w.v1 && w.tmp && (char *)w.k1 == (char *)w.k0 + align_up(n * 8, 256);
 }
 
 // sig_raw[0..n) (arbitrary order) -> sig_sorted in the reference's vector order; optional SoA start/end.
 // with_type: DEL calls first, then INS calls (per-type subsequences of the vector).
-static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, uint32_t depth_len, uint32_t overflow,
-                             bool with_type, SortWs &w, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out)
+// key layout of the ordering pass: start in the low bits (width from the contig length), the type bit above it
+struct KeyLayout { int start_bits, type_pos, key_bits, bucket_shift; };
+static KeyLayout key_layout(uint32_t depth_len, bool overflow, bool with_type)
+{
+    KeyLayout k;
+    // starts are < scan_start_limit(depth_len) unless the scan flagged an overflow (then the full 32 bits are sorted)
+    k.start_bits = overflow ? 32 : std::max(1, bits_of((uint64_t)scan_start_limit(depth_len) - 1));
+    k.type_pos = with_type ? k.start_bits : -1;
+    k.key_bits = k.start_bits + (with_type ? 1 : 0);
+    k.bucket_shift = std::max(0, k.key_bits - (int)BK_BITS);
+    return k;
+}
+
+// After the scan and before the host reads the counters: bucket counts of the signatures, offsets, largest bucket.
+static void bucket_prepass(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t sig_cap, uint32_t depth_len, bool with_type, ScanCounters *cnt)
+{
+    TimerScope ts(ctx, CSV_K_SORT);
+    const KeyLayout k = key_layout(depth_len, false, with_type);
+    launch_bucket_hist(ctx->stream, sig_raw, cnt, sig_cap, k.type_pos, k.bucket_shift, bucket_off(cnt), bucket_cur(cnt));
+}
+
+static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, uint32_t depth_len, uint32_t overflow, uint32_t max_bucket,
+                             ScanCounters *cnt, bool with_type, SortWs &w, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out)
 {
     if (!n) return;
     TimerScope ts(ctx, CSV_K_SORT);
-    // starts are < scan_start_limit(depth_len) unless the scan flagged an overflow (then the full 32 bits are sorted)
-    const int start_bits = overflow ? 32 : std::max(1, bits_of((uint64_t)scan_start_limit(depth_len) - 1));
-    const int type_pos = with_type ? start_bits : -1;
-    const int key_bits = start_bits + (with_type ? 1 : 0);
+    if (!overflow && max_bucket <= BK_LOCAL_MAX) {
+        const KeyLayout k = key_layout(depth_len, false, with_type);
+        launch_bucket_sort(ctx->stream, sig_raw, n, k.type_pos, k.bucket_shift, bucket_off(cnt), bucket_cur(cnt), w.sig_tmp, sig_sorted, start_out, end_out);
+        return;
+    }
+    const KeyLayout kl = key_layout(depth_len, overflow != 0, with_type);
+    const int type_pos = kl.type_pos, key_bits = kl.key_bits;
     launch_sig_make_keys(ctx->stream, sig_raw, n, 0, type_pos, w.k0, w.v0);
     const int in_out = launch_radix_sort_u64(ctx->stream, w.k0, w.v0, w.k1, w.v1, n, key_bits, w.tmp);
     launch_sig_fix_ties_gather(ctx->stream, sig_raw, in_out ? w.k1 : w.k0, in_out ? w.v1 : w.v0, n, sig_sorted, start_out, end_out);
@@ -352,6 +383,7 @@ int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, 
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
         launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, min_oplen, min_mapq, 1, sig_raw, cap, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt);
     }
+    if (cap) bucket_prepass(ctx, sig_raw, cap, depth_len, false, dr.cnt);
     ScanCounters h;
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
     const uint64_t n = h.n_sig;
@@ -362,7 +394,7 @@ int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, 
     SortWs w;
     csv_sig *sig_sorted = (csv_sig *)arena_alloc(ctx->work, n * sizeof(csv_sig));
     if (!sortws_carve(ctx->work, n, w) || !sig_sorted) { ctx->err = "arena exhausted (sort)"; return CSV_ENOMEM; }
-    order_signatures(ctx, sig_raw, n, depth_len, h.max_start, false, w, sig_sorted, nullptr, nullptr);
+    order_signatures(ctx, sig_raw, n, depth_len, h.max_start, h.max_len, dr.cnt, false, w, sig_sorted, nullptr, nullptr);
     CSV_HIP(ctx, hipMemcpyAsync(out, sig_sorted, n * sizeof(csv_sig), hipMemcpyDeviceToHost, ctx->stream));
     CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CSV_OK;
@@ -652,7 +684,7 @@ static csv_shard *shard_common(csv_ctx *ctx, csv_shard *sh)
     ok &= hipMalloc((void **)&sh->q_start, n * 4 + 16) == hipSuccess;
     ok &= hipMalloc((void **)&sh->q_end, n * 4 + 16) == hipSuccess;
     ok &= hipMalloc((void **)&sh->depth, (size_t)sh->depth_len * 4 + 16) == hipSuccess;
-    ok &= hipMalloc((void **)&sh->counters, 256) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->counters, kCntBytes) == hipSuccess;
     ok &= hipMalloc((void **)&sh->ckpt, ckpt_bytes(sh->d.n_cigar)) == hipSuccess;
     sh->sig_cap = std::max<uint64_t>(1u << 18, n * 2);
     ok &= hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)) == hipSuccess;
@@ -814,12 +846,13 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
     ScanCounters h;
     int rc;
     for (int attempt = 0;; attempt++) {
-        CSV_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(ScanCounters), s));
+        CSV_HIP(ctx, hipMemsetAsync(cnt, 0, kCntBytes, s));
         {
             TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
             launch_cigar_scan(s, ctx->n_cu, sh->d, sh->depth_len, min_oplen, min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
                               sh->q_start, sh->q_end, sh->ckpt, cnt);
         }
+        bucket_prepass(ctx, sh->sig_raw, sh->sig_cap, sh->depth_len, true, cnt);
         if ((rc = read_counters(ctx, cnt, h))) return rc;                 // the one mid-pipeline host sync
         if (h.n_sig <= sh->sig_cap) break;
         if (attempt) { ctx->err = "pipeline: signature buffer overflow twice"; return CSV_ENOMEM; }
@@ -828,6 +861,7 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
         CSV_HIP(ctx, hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)));
     }
     const uint64_t n = h.n_sig, n_del = h.n_del, n_ins = n - n_del;
+    const uint32_t max_bucket = h.max_len;
 
     // shard scratch: sorted signatures, SoA start/end, labels, sort + dbscan workspace (grow-only)
     const uint64_t n_big = n;
@@ -853,7 +887,7 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
     launch_min_pts(s, cnt, min_pts_pct);
 
     // ordering: DEL calls then INS calls, each in chr_sv_calls order
-    order_signatures(ctx, sh->sig_raw, n, sh->depth_len, h.max_start, true, w, sig_sorted, st, en);
+    order_signatures(ctx, sh->sig_raw, n, sh->depth_len, h.max_start, max_bucket, cnt, true, w, sig_sorted, st, en);
 
     // per-type interval DBSCAN (mergeSVs walks DEL ... INS, sv_object.cpp:62-68)
     {

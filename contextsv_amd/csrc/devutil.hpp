@@ -77,19 +77,29 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// The reference's interval metric, evaluated in the same IEEE double expression
-// (dbscan.cpp:69-81): 1.0 - std::min(ov/len1, ov/len2) <= eps, with std::min(a,b) = (b<a)?b:a
-// (NaN-asymmetric when a length is 0). Build with -ffp-contract=off.
+// The reference's interval metric (dbscan.cpp:69-81): 1.0 - std::min(ov/len1, ov/len2) <= eps in IEEE double, with
+// std::min(a,b) = (b<a)?b:a (NaN-asymmetric when a length is 0). Build with -ffp-contract=off.
+// For positive lengths min(ov/len1, ov/len2) IS ov/max(len1,len2) bit for bit (division is correctly rounded, hence monotonic
+// in the divisor), so one division decides; and a single-precision estimate settles every pair that is not within 1e-4 of the
+// threshold, which leaves the double division to the rare boundary case. Lengths <= 0 take the literal expression.
 __device__ __forceinline__ bool iv_neighbor(uint32_t s1, uint32_t e1, uint32_t s2, uint32_t e2, double eps)
 {
-    int a = min((int)e1, (int)e2);
-    int b = max((int)s1, (int)s2);
-    int overlap = max(0, a - b);
-    int length1 = (int)(e1 - s1);
-    int length2 = (int)(e2 - s2);
-    double x = (double)overlap / (double)length1;
-    double y = (double)overlap / (double)length2;
-    double mn = (y < x) ? y : x;
+    const int a = min((int)e1, (int)e2);
+    const int b = max((int)s1, (int)s2);
+    const int overlap = max(0, a - b);
+    const int length1 = (int)(e1 - s1);
+    const int length2 = (int)(e2 - s2);
+    if (length1 > 0 && length2 > 0) {
+        const int lmax = max(length1, length2);
+        const float q = __fdividef((float)overlap, (float)lmax);      // relative error << 1e-4
+        const float t = (float)(1.0 - eps);
+        if (q > t + 1e-4f) return true;
+        if (q < t - 1e-4f) return false;
+        return (1.0 - (double)overlap / (double)lmax) <= eps;
+    }
+    const double x = (double)overlap / (double)length1;
+    const double y = (double)overlap / (double)length2;
+    const double mn = (y < x) ? y : x;
     return (1.0 - mn) <= eps;
 }
 

@@ -17,9 +17,11 @@
 // padded by 2 bp because acceptance is decided by the ROUNDED double expression; inside the window
 // the reference's exact expression is evaluated (devutil.hpp iv_neighbor). So O(n*w) instead of O(n^2).
 //
-// Five launches (for one set or for two sets side by side): neighbour count (+ union-find init) -> lock-free union-find over core pairs (agent-scope atomics; larger
-// root linked under smaller, so a component's root is its minimum original index) -> roots flagged
-// and ranked by an exclusive scan in original-index space -> labels.
+// Five launches (for one set or for two sets side by side): neighbour count (+ union-find init) -> union-find over core
+// pairs inside 256-point tiles in LDS -> the pairs that cross a tile border through a lock-free global union-find (agent-scope
+// atomics); in both the larger root is linked under the smaller, so a component's root is its minimum original index ->
+// roots flagged and ranked in original-index space (per-tile ranks + a last-workgroup scan of the tile totals when positions
+// are original indices, else an exclusive scan) -> labels.
 // The same machinery, instantiated with the 1-D metric |a-b| <= eps, serves DBSCAN1D segments that
 // are too large for the LDS kernel (dbscan1d.hip).
 #include "../common.hpp"
@@ -29,59 +31,95 @@ namespace csv {
 
 constexpr uint32_t NONE = 0xffffffffu;
 
+// A metric names the per-point record (Elem), how to fetch it, its sort key, the key window that can hold neighbours, and the
+// reference's neighbour predicate. Kernels stage the Elems of a tile (plus a halo) in LDS: the window loops are chains of
+// dependent loads, and an LDS hit costs a tenth of an L2 hit.
 struct IntervalMetric {
+    struct Elem { uint32_t s, e; };
     const uint32_t *s, *e;
     double eps;
-    __device__ __forceinline__ uint32_t key(uint64_t i) const { return s[i]; }
-    __device__ __forceinline__ void window(uint64_t i, uint64_t &lo, uint64_t &hi) const
+    __device__ __forceinline__ Elem load(uint64_t i) const { return Elem{s[i], e[i]}; }
+    __device__ __forceinline__ static uint32_t key(const Elem &a) { return a.s; }
+    __device__ __forceinline__ void window(const Elem &a, uint64_t &lo, uint64_t &hi) const
     {
-        const uint32_t si = s[i];
-        const int li = (int)(e[i] - si);
+        const int li = (int)(a.e - a.s);
         const double l = li > 0 ? (double)li : 0.0;
         const uint64_t wf = (uint64_t)(eps * l) + 2;
         const uint64_t wb = (uint64_t)(eps * l / (1.0 - eps)) + 2;
-        hi = (uint64_t)si + wf;
-        lo = (uint64_t)si > wb ? (uint64_t)si - wb : 0;
+        hi = (uint64_t)a.s + wf;
+        lo = (uint64_t)a.s > wb ? (uint64_t)a.s - wb : 0;
     }
-    __device__ __forceinline__ bool nb(uint64_t i, uint64_t j) const { return iv_neighbor(s[i], e[i], s[j], e[j], eps); }
+    __device__ __forceinline__ bool nb(const Elem &a, const Elem &b) const { return iv_neighbor(a.s, a.e, b.s, b.e, eps); }
 };
 
 struct PointMetric {                   // p = points sorted ascending (int order); keys biased by 2^31 so unsigned order == int order
+    struct Elem { int32_t p; };
     const int32_t *p;
     double eps;
-    __device__ __forceinline__ uint32_t key(uint64_t i) const { return (uint32_t)p[i] ^ 0x80000000u; }
-    __device__ __forceinline__ void window(uint64_t i, uint64_t &lo, uint64_t &hi) const
+    __device__ __forceinline__ Elem load(uint64_t i) const { return Elem{p[i]}; }
+    __device__ __forceinline__ static uint32_t key(const Elem &a) { return (uint32_t)a.p ^ 0x80000000u; }
+    __device__ __forceinline__ void window(const Elem &a, uint64_t &lo, uint64_t &hi) const
     {
-        const uint64_t w = (uint64_t)eps + 1, k = key(i);
+        const uint64_t w = (uint64_t)eps + 1, k = key(a);
         hi = k + w;
         lo = k > w ? k - w : 0;
     }
-    __device__ __forceinline__ bool nb(uint64_t i, uint64_t j) const
+    __device__ __forceinline__ bool nb(const Elem &a, const Elem &b) const
     {   // dbscan1d.cpp:68-70: std::abs(int - int) converted to double, <= epsilon
-        return (double)abs(p[i] - p[j]) <= eps;
+        return (double)abs(a.p - b.p) <= eps;
     }
 };
+
+constexpr int UF_TILE = 256;           // points per workgroup
+constexpr int DB_HALO = 128;           // staged on each side of the tile; windows that reach further read global memory
+
+// Elems of positions [t0 - DB_HALO, t0 + UF_TILE + DB_HALO) in LDS
+template <class M>
+struct Staged {
+    typename M::Elem *sh;
+    int64_t first;                     // position of sh[0]
+    const M &m;
+    __device__ __forceinline__ typename M::Elem operator()(uint64_t j) const
+    {
+        const int64_t k = (int64_t)j - first;
+        return (k >= 0 && k < UF_TILE + 2 * DB_HALO) ? sh[k] : m.load(j);
+    }
+};
+template <class M>
+__device__ __forceinline__ Staged<M> stage_tile(const M &m, typename M::Elem *sh, uint64_t t0, uint64_t n)
+{
+    const int64_t first = (int64_t)t0 - DB_HALO;
+    for (int k = threadIdx.x; k < UF_TILE + 2 * DB_HALO; k += UF_TILE) {
+        const int64_t idx = first + k;
+        if (idx >= 0 && (uint64_t)idx < n) sh[k] = m.load((uint64_t)idx);
+    }
+    __syncthreads();
+    return Staged<M>{sh, first, m};
+}
 
 // Two independent point sets can share every launch: positions [0, split) are one set, [split, n) the other (the DEL
 // and INS calls of a chromosome). A window never leaves its own set; cluster ids restart at 0 in the second set.
 template <class M>
-__global__ void db_count_kernel(M m, uint64_t n, uint64_t split, int min_pts_imm, const int *__restrict__ d_min_pts,
+__global__ void __launch_bounds__(UF_TILE) db_count_kernel(M m, uint64_t n, uint64_t split, int min_pts_imm, const int *__restrict__ d_min_pts,
                                 const uint32_t *__restrict__ oid, uint8_t *__restrict__ core, uint32_t *__restrict__ parent,
-                                uint32_t *__restrict__ is_root)
+                                uint32_t *__restrict__ is_root, unsigned int *__restrict__ ticket)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == n) is_root[n] = 0;
+    __shared__ typename M::Elem sh[UF_TILE + 2 * DB_HALO];
+    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE, i = t0 + threadIdx.x;
+    const Staged<M> at = stage_tile(m, sh, t0, n);
+    if (i == n) { is_root[n] = 0; *ticket = 0; }
     if (i >= n) return;
     const uint32_t me = oid ? oid[i] : (uint32_t)i;
     parent[me] = me;                                   // union-find + root flags start here (no separate init launch)
     is_root[me] = 0;
     const int min_pts = d_min_pts ? *d_min_pts : min_pts_imm;
     const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
+    const typename M::Elem mine = at(i);
     uint64_t lo, hi;
-    m.window(i, lo, hi);
+    m.window(mine, lo, hi);
     int cnt = 0;
-    for (uint64_t j = i; j < s1 && (uint64_t)m.key(j) <= hi; j++) cnt += m.nb(i, j);
-    for (uint64_t j = i; j-- > s0 && (uint64_t)m.key(j) >= lo;) cnt += m.nb(i, j);
+    for (uint64_t j = i; j < s1; j++) { const typename M::Elem o = at(j); if ((uint64_t)M::key(o) > hi) break; cnt += m.nb(mine, o); }
+    for (uint64_t j = i; j-- > s0;) { const typename M::Elem o = at(j); if ((uint64_t)M::key(o) < lo) break; cnt += m.nb(mine, o); }
     core[i] = cnt >= min_pts;
 }
 
@@ -110,17 +148,143 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
     }
 }
 
+__device__ __forceinline__ uint32_t lds_ld(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ uint32_t lds_find(uint32_t *lpar, uint32_t x)
+{
+    for (;;) {
+        const uint32_t p = lds_ld(&lpar[x]);
+        if (p == x) return x;
+        const uint32_t gp = lds_ld(&lpar[p]);
+        if (gp != p) __hip_atomic_store(&lpar[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // path halving
+        x = p;
+    }
+}
+
+// Pairs with both ends in one tile of UF_TILE consecutive positions: union-find in LDS (a cluster's members are neighbours in
+// the sorted order, so this is nearly every pair), then each core point's parent is written flat: parent[me] = its tile root.
 template <class M>
-__global__ void db_union_kernel(M m, uint64_t n, uint64_t split, const uint8_t *__restrict__ core, const uint32_t *__restrict__ oid, uint32_t *parent)
+__global__ void __launch_bounds__(UF_TILE) db_union_local_kernel(M m, uint64_t n, uint64_t split, const uint8_t *__restrict__ core,
+                                                                 const uint32_t *__restrict__ oid, uint32_t *__restrict__ parent)
+{
+    __shared__ uint32_t lpar[UF_TILE], loid[UF_TILE];
+    __shared__ typename M::Elem sh[UF_TILE];
+    __shared__ uint8_t lcore[UF_TILE];
+    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE, i = t0 + threadIdx.x;
+    const uint32_t li = threadIdx.x;
+    lpar[li] = li;
+    loid[li] = i < n ? (oid ? oid[i] : (uint32_t)i) : NONE;
+    lcore[li] = i < n ? core[i] : 0;
+    if (i < n) sh[li] = m.load(i);
+    __syncthreads();
+    const bool active = lcore[li] != 0;
+    if (active) {
+        const typename M::Elem mine = sh[li];
+        uint64_t lo, hi;
+        m.window(mine, lo, hi);
+        const uint64_t s1 = i < split ? split : n;
+        const uint32_t l_end = (uint32_t)(min(t0 + UF_TILE, s1) - t0);
+        for (uint32_t lj = li + 1; lj < l_end; lj++) {
+            const typename M::Elem o = sh[lj];
+            if ((uint64_t)M::key(o) > hi) break;
+            if (!lcore[lj] || !m.nb(mine, o)) continue;
+            uint32_t a = li, b = lj;
+            for (;;) {
+                a = lds_find(lpar, a);
+                b = lds_find(lpar, b);
+                if (a == b) break;
+                if (loid[a] > loid[b]) { const uint32_t t = a; a = b; b = t; }      // the smaller original index stays root
+                if (atomicCAS(&lpar[b], b, a) == b) break;
+            }
+        }
+    }
+    __syncthreads();
+    if (active) parent[loid[li]] = loid[lds_find(lpar, li)];
+}
+
+// Pairs whose later end lies beyond the tile of the earlier one.
+template <class M>
+__global__ void db_union_cross_kernel(M m, uint64_t n, uint64_t split, const uint8_t *__restrict__ core, const uint32_t *__restrict__ oid, uint32_t *parent)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !core[i]) return;
-    uint64_t lo, hi;
-    m.window(i, lo, hi);
     const uint64_t s1 = i < split ? split : n;
+    const uint64_t tile_end = (i / UF_TILE + 1) * UF_TILE;
+    if (tile_end >= s1) return;
+    const typename M::Elem mine = m.load(i);
+    uint64_t lo, hi;
+    m.window(mine, lo, hi);
+    if ((uint64_t)M::key(m.load(tile_end)) > hi) return;  // the window ends inside the tile
     const uint32_t me = oid ? oid[i] : (uint32_t)i;
-    for (uint64_t j = i + 1; j < s1 && (uint64_t)m.key(j) <= hi; j++)
-        if (core[j] && m.nb(i, j)) uf_union(parent, me, oid ? oid[j] : (uint32_t)j);
+    // After the local pass every point of a tile component carries the same parent, so consecutive neighbours that belong to one
+    // component need a single union; each union is a chain of agent-scope round trips, which is what this kernel's time is made of.
+    uint32_t last_parent = NONE;
+    for (uint64_t j = tile_end; j < s1; j++) {
+        const typename M::Elem o = m.load(j);
+        if ((uint64_t)M::key(o) > hi) break;
+        if (!core[j] || !m.nb(mine, o)) continue;
+        const uint32_t oj = oid ? oid[j] : (uint32_t)j;
+        const uint32_t pj = uf_load(&parent[oj]);
+        if (pj == last_parent) continue;
+        last_parent = pj;
+        uf_union(parent, me, oj);
+    }
+}
+
+// Positions are original indices (oid == nullptr): roots, their rank inside the tile, and — by the workgroup that finishes
+// last — the exclusive scan of the tile totals. cid(k) = tile_prefix[k / UF_TILE] + rank[k] = number of roots below k.
+__global__ void __launch_bounds__(UF_TILE) db_roots_rank_kernel(uint64_t n, const uint8_t *__restrict__ core, const uint32_t *__restrict__ parent,
+                                                                uint32_t *__restrict__ root_of, uint32_t *__restrict__ rank,
+                                                                uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_prefix,
+                                                                unsigned int *__restrict__ ticket, uint32_t n_tiles)
+{
+    __shared__ uint32_t wtot[UF_TILE / 64];
+    __shared__ bool last;
+    const uint64_t i = (uint64_t)blockIdx.x * UF_TILE + threadIdx.x;
+    bool is_root = false;
+    if (i < n) {
+        uint32_t r = NONE;
+        if (core[i]) {
+            uint32_t x = (uint32_t)i;
+            for (;;) { const uint32_t p = parent[x]; if (p == x) break; x = p; }   // unions finished: plain loads
+            r = x;
+            is_root = x == (uint32_t)i;
+        }
+        root_of[i] = r;
+    }
+    const uint64_t bal = __ballot(is_root);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) wtot[w] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = (uint32_t)__popcll(bal & lanemask_lt());
+    uint32_t total = 0;
+    for (int k = 0; k < UF_TILE / 64; k++) { if (k < w) before += wtot[k]; total += wtot[k]; }
+    if (i <= n) rank[i] = before;                        // rank[n] closes the last tile (cid(n) is never asked for)
+    if (threadIdx.x == 0) {
+        tile_count[blockIdx.x] = total;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // exclusive scan of the tile totals, UF_TILE at a time
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_tiles; c0 += UF_TILE) {
+        const uint32_t k = c0 + threadIdx.x;
+        const uint32_t v = k < n_tiles ? __hip_atomic_load(&tile_count[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t inc = wave_incl_sum_dpp(v);
+        if ((threadIdx.x & 63) == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t base = carry_s;
+        for (int q = 0; q < w; q++) base += wtot[q];
+        if (k < n_tiles) tile_prefix[k] = base + inc - v;
+        __syncthreads();
+        if (threadIdx.x == UF_TILE - 1) carry_s = base + inc;
+        __syncthreads();
+    }
 }
 
 __global__ void db_roots_kernel(uint64_t n, const uint8_t *__restrict__ core, const uint32_t *__restrict__ oid,
@@ -136,33 +300,49 @@ __global__ void db_roots_kernel(uint64_t n, const uint8_t *__restrict__ core, co
     if (x == me) is_root[me] = 1;
 }
 
-template <class M>
-__global__ void db_label_kernel(M m, uint64_t n, uint64_t split, const uint32_t *__restrict__ oid, const uint32_t *__restrict__ root_of,
-                                const uint32_t *__restrict__ cid_raw, int32_t *__restrict__ labels)
+// number of roots with an original index below k: from the exclusive scan, or from tile prefix + rank inside the tile
+struct ScanCid { const uint32_t *c; __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return c[k]; } };
+struct TileCid {
+    const uint32_t *tile_prefix, *rank;
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return tile_prefix[k / UF_TILE] + rank[k]; }
+};
+
+template <class M, class C>
+__global__ void __launch_bounds__(UF_TILE) db_label_kernel(M m, uint64_t n, uint64_t split, const uint32_t *__restrict__ oid, const uint32_t *__restrict__ root_of,
+                                C cid_raw, int32_t *__restrict__ labels)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ typename M::Elem sh[UF_TILE + 2 * DB_HALO];
+    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE, i = t0 + threadIdx.x;
+    const Staged<M> at = stage_tile(m, sh, t0, n);
     if (i >= n) return;
     const uint32_t me = oid ? oid[i] : (uint32_t)i;
     const uint32_t r = root_of[i];
     // ids of the second set restart at 0: subtract the number of roots of the first set (only used with oid == nullptr,
-    // where original index == position, so cid_raw[split] is that count)
-    const uint32_t id0 = (i >= split && split < n) ? cid_raw[split] : 0u;
+    // where original index == position, so cid_raw(split) is that count)
+    const uint32_t id0 = (i >= split && split < n) ? cid_raw((uint32_t)split) : 0u;
     const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
-    struct { const uint32_t *p; uint32_t off; __device__ uint32_t operator[](uint32_t k) const { return p[k] - off; } } cid{cid_raw, id0};
+    struct { C c; uint32_t off; __device__ uint32_t operator[](uint32_t k) const { return c(k) - off; } } cid{cid_raw, id0};
     if (r != NONE) { labels[me] = (int32_t)cid[r]; return; }
+    const typename M::Elem mine = at(i);
     uint64_t lo, hi;
-    m.window(i, lo, hi);
+    m.window(mine, lo, hi);
     int32_t max_start = -1, min_core = INT32_MAX;
-    for (uint64_t j = i + 1; j < s1 && (uint64_t)m.key(j) <= hi; j++) {
+    for (uint64_t j = i + 1; j < s1; j++) {
+        const typename M::Elem o = at(j);
+        if ((uint64_t)M::key(o) > hi) break;
+        if (!m.nb(mine, o)) continue;
         const uint32_t rj = root_of[j];
-        if (rj != NONE && m.nb(i, j)) {
+        if (rj != NONE) {
             const int32_t c = (int32_t)cid[rj];
             if (rj == (oid ? oid[j] : (uint32_t)j)) max_start = max(max_start, c); else min_core = min(min_core, c);
         }
     }
-    for (uint64_t j = i; j-- > s0 && (uint64_t)m.key(j) >= lo;) {
+    for (uint64_t j = i; j-- > s0;) {
+        const typename M::Elem o = at(j);
+        if ((uint64_t)M::key(o) < lo) break;
+        if (!m.nb(mine, o)) continue;
         const uint32_t rj = root_of[j];
-        if (rj != NONE && m.nb(i, j)) {
+        if (rj != NONE) {
             const int32_t c = (int32_t)cid[rj];
             if (rj == (oid ? oid[j] : (uint32_t)j)) max_start = max(max_start, c); else min_core = min(min_core, c);
         }
@@ -173,7 +353,8 @@ __global__ void db_label_kernel(M m, uint64_t n, uint64_t split, const uint32_t 
 // tmp: core u8[n] | parent u32[n] | root_of u32[n] | is_root/cid u32[n+1] | scan tmp
 size_t dbscan_tmp_bytes(uint64_t n)
 {
-    return align_up(n, 256) + 2 * align_up(n * 4, 256) + align_up((n + 1) * 4, 256) + exclusive_sum_tmp_bytes(n + 1);
+    const uint64_t nt = (n + UF_TILE) / UF_TILE + 1;
+    return align_up(n, 256) + 2 * align_up(n * 4, 256) + align_up((n + 1) * 4, 256) + exclusive_sum_tmp_bytes(n + 1) + 2 * align_up(nt * 4, 256) + 256;
 }
 
 template <class M>
@@ -186,13 +367,23 @@ static void run_dbscan(hipStream_t s, M m, const uint32_t *oid, uint64_t n, uint
     uint32_t *parent = (uint32_t *)p;  p += align_up(n * 4, 256);
     uint32_t *root_of = (uint32_t *)p; p += align_up(n * 4, 256);
     uint32_t *cid = (uint32_t *)p;     p += align_up((n + 1) * 4, 256);
-    void *es_tmp = p;
+    void *es_tmp = p;                  p += exclusive_sum_tmp_bytes(n + 1);
+    const uint32_t n_tiles = (uint32_t)((n + UF_TILE) / UF_TILE);          // tiles of positions 0..n (rank[n] included)
+    uint32_t *tile_count = (uint32_t *)p;  p += align_up(((uint64_t)n_tiles + 1) * 4, 256);
+    uint32_t *tile_prefix = (uint32_t *)p; p += align_up(((uint64_t)n_tiles + 1) * 4, 256);
+    unsigned int *ticket = (unsigned int *)p;
     const dim3 grid((unsigned)((n + 255) / 256)), grid1((unsigned)((n + 1 + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(db_count_kernel<M>, grid1, blk, 0, s, m, n, split, min_pts, d_min_pts, oid, core, parent, cid);
-    hipLaunchKernelGGL(db_union_kernel<M>, grid, blk, 0, s, m, n, split, core, oid, parent);
-    hipLaunchKernelGGL(db_roots_kernel, grid, blk, 0, s, n, core, oid, parent, root_of, cid);
-    launch_exclusive_sum_u32(s, cid, n + 1, es_tmp);
-    hipLaunchKernelGGL(db_label_kernel<M>, grid, blk, 0, s, m, n, split, oid, root_of, cid, labels);
+    hipLaunchKernelGGL(db_count_kernel<M>, grid1, blk, 0, s, m, n, split, min_pts, d_min_pts, oid, core, parent, cid, ticket);
+    hipLaunchKernelGGL(db_union_local_kernel<M>, grid, dim3(UF_TILE), 0, s, m, n, split, core, oid, parent);
+    hipLaunchKernelGGL(db_union_cross_kernel<M>, grid, blk, 0, s, m, n, split, core, oid, parent);
+    if (!oid) {
+        hipLaunchKernelGGL(db_roots_rank_kernel, dim3(n_tiles), dim3(UF_TILE), 0, s, n, core, parent, root_of, cid, tile_count, tile_prefix, ticket, n_tiles);
+        hipLaunchKernelGGL((db_label_kernel<M, TileCid>), grid, blk, 0, s, m, n, split, oid, root_of, TileCid{tile_prefix, cid}, labels);
+    } else {
+        hipLaunchKernelGGL(db_roots_kernel, grid, blk, 0, s, n, core, oid, parent, root_of, cid);
+        launch_exclusive_sum_u32(s, cid, n + 1, es_tmp);
+        hipLaunchKernelGGL((db_label_kernel<M, ScanCid>), grid, blk, 0, s, m, n, split, oid, root_of, ScanCid{cid}, labels);
+    }
 }
 
 void launch_dbscan_iv_sorted(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint32_t *oid,

@@ -235,6 +235,122 @@ int launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, u
     return (passes & 1) ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------- bucket ordering (the common case)
+// A chromosome yields 1e4..1e6 signatures whose starts spread over the contig, so one most-significant-digit split into
+// BK_N buckets leaves a few dozen records per bucket; a wave then ranks its bucket with the full comparator
+// ((type, start) asc, end asc, (read, query offset) desc = the reference's lower_bound insertion order) and writes the final
+// records. Four launches instead of the fourteen of the LSD radix path (which stays as the fallback for skewed input: a
+// bucket above BK_LOCAL_MAX, or starts that overflow the key).
+__device__ __forceinline__ uint32_t bk_bucket(const csv_sig &sg, int type_pos, int shift)
+{
+    uint64_t k = sg.start;
+    if (type_pos >= 0 && (sg.qpos_kind & 3u) != CSV_KIND_DEL) k |= 1ull << type_pos;
+    const uint64_t b = k >> shift;
+    return b < BK_N ? (uint32_t)b : BK_N - 1u;          // starts beyond the key width only occur with the overflow flag (fallback)
+}
+
+__global__ void bk_hist_kernel(const csv_sig *__restrict__ sig, const ScanCounters *__restrict__ cnt, uint64_t cap, int type_pos, int shift,
+                               uint32_t *__restrict__ hist)
+{
+    const uint64_t n = cnt->n_sig < cap ? cnt->n_sig : cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&hist[bk_bucket(sig[i], type_pos, shift)], 1u);
+}
+
+// one workgroup: counts -> exclusive offsets (hist in place) + scatter cursors, largest bucket -> cnt->max_len
+__global__ void __launch_bounds__(1024) bk_prep_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ cur, ScanCounters *__restrict__ cnt)
+{
+    constexpr int PER = BK_N / 1024;
+    __shared__ uint32_t wsum[16], wmax[16];
+    uint32_t v[PER], tot = 0, mx = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { v[k] = hist[threadIdx.x * PER + k]; tot += v[k]; mx = max(mx, v[k]); }
+    const uint32_t incl = wave_incl_sum_dpp(tot);
+    mx = wave_max(mx);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 63) { wsum[w] = incl; wmax[w] = mx; }
+    __syncthreads();
+    uint32_t base = 0, gmax = 0;
+    for (int k = 0; k < 16; k++) { if (k < w) base += wsum[k]; gmax = max(gmax, wmax[k]); }
+    uint32_t run = base + incl - tot;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { hist[threadIdx.x * PER + k] = run; cur[threadIdx.x * PER + k] = run; run += v[k]; }
+    if (threadIdx.x == 0) cnt->max_len = gmax;
+}
+
+__global__ void bk_scatter_kernel(const csv_sig *__restrict__ sig, uint64_t n, int type_pos, int shift, uint32_t *__restrict__ cur,
+                                  csv_sig *__restrict__ tmp)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const csv_sig sg = sig[i];
+    tmp[atomicAdd(&cur[bk_bucket(sg, type_pos, shift)], 1u)] = sg;
+}
+
+// a precedes b in the reference's vector
+__device__ __forceinline__ bool sig_before(const csv_sig &a, uint64_t ka, const csv_sig &b, uint64_t kb)
+{
+    if (ka != kb) return ka < kb;
+    if (a.end != b.end) return a.end < b.end;
+    if (a.read != b.read) return a.read > b.read;
+    return a.qpos_kind > b.qpos_kind;
+}
+
+__global__ void __launch_bounds__(256) bk_local_kernel(const csv_sig *__restrict__ tmp, const uint32_t *__restrict__ off, uint64_t n, int type_pos,
+                                                       csv_sig *__restrict__ sig_sorted, uint32_t *__restrict__ start_out, uint32_t *__restrict__ end_out)
+{
+    __shared__ csv_sig stage[4][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * 4 + w;
+    const uint32_t base = off[b];
+    const uint32_t m = (b + 1 < BK_N ? off[b + 1] : (uint32_t)n) - base;
+    for (uint32_t j0 = 0; j0 < m; j0 += 64) {
+        const uint32_t j = j0 + l;
+        csv_sig me{};
+        uint64_t km = 0;
+        if (j < m) {
+            me = tmp[base + j];
+            km = me.start;
+            if (type_pos >= 0 && (me.qpos_kind & 3u) != CSV_KIND_DEL) km |= 1ull << type_pos;
+        }
+        uint32_t rank = 0;
+        for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+            const uint32_t cn = min(64u, m - c0);
+            if (c0 + l < m) stage[w][l] = tmp[base + c0 + l];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // this wave's staging stores before its broadcast reads
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t t = 0; t < cn; t++) {
+                const csv_sig o = stage[w][t];
+                uint64_t ko = o.start;
+                if (type_pos >= 0 && (o.qpos_kind & 3u) != CSV_KIND_DEL) ko |= 1ull << type_pos;
+                // identical records (never produced by the scan) keep their bucket order so that the result stays a permutation
+                const bool same = ko == km && o.end == me.end && o.read == me.read && o.qpos_kind == me.qpos_kind;
+                rank += (sig_before(o, ko, me, km) || (same && c0 + t < j)) ? 1u : 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // reads done before the next chunk overwrites the stage
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (j < m) {
+            sig_sorted[base + rank] = me;
+            if (start_out) { start_out[base + rank] = me.start; end_out[base + rank] = me.end; }
+        }
+    }
+}
+
+void launch_bucket_hist(hipStream_t s, const csv_sig *sig, ScanCounters *cnt, uint64_t cap, int type_pos, int shift, uint32_t *hist, uint32_t *cur)
+{
+    hipLaunchKernelGGL(bk_hist_kernel, dim3(256), dim3(256), 0, s, sig, cnt, cap, type_pos, shift, hist);
+    hipLaunchKernelGGL(bk_prep_kernel, dim3(1), dim3(1024), 0, s, hist, cur, cnt);
+}
+
+void launch_bucket_sort(hipStream_t s, const csv_sig *sig_raw, uint64_t n, int type_pos, int shift, const uint32_t *off, uint32_t *cur,
+                        csv_sig *tmp, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(bk_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sig_raw, n, type_pos, shift, cur, tmp);
+    hipLaunchKernelGGL(bk_local_kernel, dim3(BK_N / 4), dim3(256), 0, s, tmp, off, n, type_pos, sig_sorted, start_out, end_out);
+}
+
 // ------------------------------------------------------------------------------- signature ordering
 // key = [type bit | start]; type bit 0 = DEL, 1 = INS so the DEL calls come first (mergeSVs walks DEL, DUP, INV,
 // INS, BND — sv_object.cpp:62-68). type_bit_pos < 0: no type bit (the interleaved order of the reference's single

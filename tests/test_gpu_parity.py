@@ -200,3 +200,31 @@ def test_chr_pipeline_matches_oracle(ctx, oracle):
                 assert np.array_equal(g, o)
     finally:
         sh.free()
+
+
+def _pileup(n_reads, n_distinct_pos):
+    """Many reads carrying the same events at the same loci: every signature start is shared by hundreds or thousands of
+    records, which is what decides between the ordering pass's bucket path and its radix fallback."""
+    M, I, D, S = 0, 1, 2, 4
+    pos = np.sort(np.arange(n_reads) % n_distinct_pos * 7 + 1000)
+    cig = [[(S, 60 + r % 3), (M, 500 - (p - 1000)), (D, 80 + (r % 2)), (M, 300), (I, 70), (M, 200 + r % 5)] for r, p in enumerate(pos)]
+    reads = Reads.from_cigar_lists(pos, np.zeros(n_reads, np.uint16), np.full(n_reads, 60, np.uint8), cig)
+    return reads, 20_001
+
+
+@pytest.mark.parametrize("n_reads,n_pos", [(1500, 1), (1500, 40), (5000, 1), (5000, 3)])
+def test_ordering_with_heavy_ties(ctx, oracle, n_reads, n_pos):
+    """(1500, *): one bucket holds up to 1500 records (several 64-record chunks per wave); (5000, *): above BK_LOCAL_MAX, the
+    LSD radix fallback orders them. Both must give the reference's vector order (end ascending, then reverse insertion)."""
+    reads, depth_len = _pileup(n_reads, n_pos)
+    _same_sigs(ctx.cigar_scan(reads, depth_len), oracle.cigar_scan(reads, depth_len))
+    sh = ctx.upload(reads, depth_len)
+    try:
+        res = sh.pipeline(eps=0.1, min_pts_pct=0.1)
+        out = sh.fetch(res)
+        sig = oracle.cigar_scan(reads, depth_len)
+        kind = sig["qpos_kind"] & 3
+        _same_sigs(out["sig_del"], sig[kind == 1]); _same_sigs(out["sig_ins"], sig[kind != 1])
+        assert res.n_sig == 3 * n_reads
+    finally:
+        sh.free()
