@@ -69,6 +69,9 @@ ABI = {
     "csvgpu_shard_wrap_dev": (_P, [_P, C.POINTER(csv_reads), C.c_uint32]),
     "csvgpu_shard_free": (None, [_P, _P]),
     "csvgpu_chr_pipeline_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.POINTER(csv_chr_result)]),
+    "csvgpu_chr_pipeline_fetch": (C.c_int, [_P, _P, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.POINTER(csv_chr_result), _P, _P, C.c_uint64]),
+    "csvgpu_host_alloc": (_P, [_P, C.c_size_t]),
+    "csvgpu_host_free": (None, [_P, _P]),
     "csvgpu_aln_intervals_resident": (C.c_int, [_P, _P, _P, _P, _P]),
     "csvgpu_window_log2_resident": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_double, _P, _P, _P]),
     "csvgpu_chr_fetch": (C.c_int, [_P, _P, C.POINTER(csv_chr_result), _P, _P]),

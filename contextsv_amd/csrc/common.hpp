@@ -50,6 +50,8 @@ struct csv_ctx {
     uint64_t     t_n[CSV_K_COUNT] = {0};
     std::string  err;
     int          n_cu = 256;
+    // csvgpu_host_alloc / csvgpu_host_free: page-locking is slow (hundreds of microseconds), so freed blocks are kept for reuse
+    std::vector<std::pair<void *, size_t>> host_live, host_pool;
 };
 
 struct csv_shard {

@@ -332,6 +332,8 @@ void csvgpu_destroy(csv_ctx *ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->work.base) (void)hipFree(ctx->work.base);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &b : ctx->host_pool) (void)hipHostFree(b.first);
+    for (auto &b : ctx->host_live) (void)hipHostFree(b.first);       // blocks the caller never returned
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -835,8 +837,56 @@ int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t by
     return CSV_OK;
 }
 
+void *csvgpu_host_alloc(csv_ctx *ctx, size_t bytes)
+{
+    if (!ctx || !bytes) return nullptr;
+    for (size_t i = 0; i < ctx->host_pool.size(); i++) {
+        if (ctx->host_pool[i].second >= bytes && ctx->host_pool[i].second <= 2 * bytes + 4096) {
+            ctx->host_live.push_back(ctx->host_pool[i]);
+            ctx->host_pool.erase(ctx->host_pool.begin() + (std::ptrdiff_t)i);
+            return ctx->host_live.back().first;
+        }
+    }
+    (void)hipSetDevice(ctx->device);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->err = "hipHostMalloc failed"; return nullptr; }
+    ctx->host_live.emplace_back(p, bytes);
+    return p;
+}
+
+void csvgpu_host_free(csv_ctx *ctx, void *p)
+{
+    if (!ctx || !p) return;
+    for (size_t i = 0; i < ctx->host_live.size(); i++) {
+        if (ctx->host_live[i].first != p) continue;
+        ctx->host_pool.push_back(ctx->host_live[i]);
+        ctx->host_live.erase(ctx->host_live.begin() + (std::ptrdiff_t)i);
+        while (ctx->host_pool.size() > 8) {                // bounded: drop the oldest
+            (void)hipHostFree(ctx->host_pool.front().first);
+            ctx->host_pool.erase(ctx->host_pool.begin());
+        }
+        return;
+    }
+}
+
+static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct, csv_chr_result *res,
+                        csv_sig *host_sig, int32_t *host_labels, uint64_t capacity, bool fetch);
+
 int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
                             csv_chr_result *res)
+{
+    return chr_pipeline(ctx, sh, min_oplen, min_mapq, eps, min_pts_pct, res, nullptr, nullptr, 0, false);
+}
+
+int csvgpu_chr_pipeline_fetch(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
+                              csv_chr_result *res, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity)
+{
+    if (capacity && (!host_sig || !host_labels)) { if (ctx) ctx->err = "pipeline_fetch: null output"; return CSV_EINVAL; }
+    return chr_pipeline(ctx, sh, min_oplen, min_mapq, eps, min_pts_pct, res, host_sig, host_labels, capacity, true);
+}
+
+static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct, csv_chr_result *res,
+                        csv_sig *host_sig, int32_t *host_labels, uint64_t capacity, bool fetch)
 {
     if (!ctx || !sh || !res) return CSV_EINVAL;
     if (!(eps >= 0.0) || !(eps < 1.0)) { ctx->err = "pipeline: eps must be in [0,1)"; return CSV_EINVAL; }
@@ -895,12 +945,18 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uin
         // DEL calls [0, n_del) and INS calls [n_del, n) are clustered side by side in the same five launches
         if (n) launch_dbscan_iv_sorted(s, st, en, nullptr, n, n_del, eps, 0, &cnt->min_pts, labels, db_tmp);
     }
+    const bool copy_out = fetch && n && n <= capacity;
+    if (copy_out) {                                                      // results ride behind the last kernel, one wait for everything
+        CSV_HIP(ctx, hipMemcpyAsync(host_sig, sig_sorted, n * sizeof(csv_sig), hipMemcpyDeviceToHost, s));
+        CSV_HIP(ctx, hipMemcpyAsync(host_labels, labels, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
     if ((rc = read_counters(ctx, cnt, h))) return rc;                     // final sync: scalars for the caller
     res->n_sig = n; res->n_del = n_del; res->n_ins = n_ins;
     res->depth_sum = h.depth_sum; res->depth_nonzero = h.depth_nonzero; res->min_pts = h.min_pts; res->mean_cov = h.mean_cov;
     res->sig_del = sig_sorted; res->sig_ins = sig_sorted + n_del;
     res->label_del = labels; res->label_ins = labels + n_del;
     res->depth = sh->depth; res->ref_end = sh->ref_end; res->q_start = sh->q_start; res->q_end = sh->q_end;
+    if (fetch && n > capacity) { ctx->err = "pipeline_fetch: host buffers too small"; return CSV_ECAPACITY; }
     return CSV_OK;
 }
 

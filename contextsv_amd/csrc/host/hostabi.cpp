@@ -170,6 +170,20 @@ int csvhost_process_resident_chromosome(csv_ctx *ctx, csv_shard *shard, const ui
     })
 }
 
+// The host half alone (no device): ordered signatures + labels -> merged calls; `reps` timed repetitions, *ms = mean time of one.
+int csvhost_merge_ordered(const csv_sig *sig, const int32_t *labels, uint64_t n_del, uint64_t n_ins, int reps, csvhost_call *out, uint64_t cap,
+                          uint64_t *n_out, double *ms)
+{
+    GUARD({
+        std::vector<SVCall> calls;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < std::max(reps, 1); r++) SVCaller::mergeOrdered(sig, labels, n_del, n_ins, nullptr, calls);
+        if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(reps, 1);
+        for (size_t i = 0; i < calls.size() && i < cap; i++) out[i] = to_pod(calls[i]);
+        *n_out = calls.size();
+    })
+}
+
 // n_steps passes over the same resident shard, software-pipelined (device chain of step i+1 overlaps the host merge of
 // step i). Returns the merged calls of the LAST step and its stats; ms_total = wall time of all steps.
 int csvhost_process_resident_pipelined(csv_ctx *ctx, csv_shard *shard, uint64_t n_steps, const uint64_t *seq_off, const uint8_t *seq,

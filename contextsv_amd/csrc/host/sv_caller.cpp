@@ -59,42 +59,63 @@ SVCall SVCaller::toSVCall(const csv_sig &s, const SeqStore *seq)
 // same std::sort comparator on an index vector, same top-20 % / middle element rule, cluster_size = bucket size.
 void SVCaller::mergeSignaturesWithLabels(const csv_sig *sig, const int32_t *labels, uint64_t n, const SeqStore *seq, std::vector<SVCall> &merged)
 {
+    // members of every label, in input order, as (length, index) pairs: the representative rule only compares lengths, and the
+    // selection below streams over this compact array instead of chasing indices into the 16-byte records
+    struct Ent { uint32_t len, idx; };
+    static thread_local std::vector<uint32_t> head, cur;
+    static thread_local std::vector<Ent> member;
     int32_t max_label = -2;
     for (uint64_t i = 0; i < n; i++) max_label = std::max(max_label, labels[i]);
     const size_t n_slots = (size_t)(max_label + 3);
-    std::vector<uint32_t> head(n_slots + 1, 0);
+    head.assign(n_slots + 1, 0);
     for (uint64_t i = 0; i < n; i++) head[(size_t)(labels[i] + 2) + 1]++;
     for (size_t s = 0; s < n_slots; s++) head[s + 1] += head[s];
-    std::vector<uint32_t> member(n), cur(head.begin(), head.end() - 1);
-    for (uint64_t i = 0; i < n; i++) member[cur[(size_t)(labels[i] + 2)]++] = (uint32_t)i;
+    cur.assign(head.begin(), head.end() - 1);
+    if (member.size() < n) member.resize(n);
+    for (uint64_t i = 0; i < n; i++) member[cur[(size_t)(labels[i] + 2)]++] = Ent{sig[i].end - sig[i].start, (uint32_t)i};
     for (size_t s = 0; s < n_slots; s++) {
         const size_t sz = head[s + 1] - head[s];
         if (sz < 2) continue;
-        uint32_t *m = member.data() + head[s];
+        Ent *m = member.data() + head[s];
         // the slot std::sort(by length desc) would fill at [top/2] — selected in O(sz), see sort_select.h
         const size_t top = (size_t)std::max(1, (int)(sz * 0.2));
-        auto by_len_desc = [&](uint32_t a, uint32_t b) { return (sig[a].end - sig[a].start) > (sig[b].end - sig[b].start); };
-        const uint32_t pick = *csvhost::std_sort_select(m, m + sz, (std::ptrdiff_t)(top / 2), by_len_desc);
+        auto by_len_desc = [](const Ent &a, const Ent &b) { return a.len > b.len; };
+        const uint32_t pick = csvhost::std_sort_select(m, m + sz, (std::ptrdiff_t)(top / 2), by_len_desc)->idx;
         SVCall rep = toSVCall(sig[pick], seq);
         rep.cluster_size = (int)sz;
         merged.push_back(rep);
     }
 }
 
+void SVCaller::DeviceOut::reserve(csv_ctx *c, uint64_t n)
+{
+    if (n <= cap && c == ctx) return;
+    release();
+    ctx = c;
+    const uint64_t want = n + n / 4 + 4096;
+    sig = (csv_sig *)csvgpu_host_alloc(c, want * sizeof(csv_sig));
+    lab = (int32_t *)csvgpu_host_alloc(c, want * sizeof(int32_t));
+    if (!sig || !lab) { release(); throw std::runtime_error("cannot allocate page-locked result buffers"); }
+    cap = want;
+}
+
 void SVCaller::runDeviceChain(const std::string &chr, csv_shard *shard, double eps, double pct, DeviceOut &out, ChrStats &st)
 {
     const double t0 = now_ms();
     csv_chr_result res;
-    check(ctx, csvgpu_chr_pipeline_dev(ctx, shard, (uint32_t)min_oplen, (uint8_t)min_mapq, eps, pct, &res), "processChromosome");
+    if (!out.cap) out.reserve(ctx, 1 << 16);
+    int rc = csvgpu_chr_pipeline_fetch(ctx, shard, (uint32_t)min_oplen, (uint8_t)min_mapq, eps, pct, &res, out.sig, out.lab, out.cap);
+    if (rc == CSV_ECAPACITY) {                         // first contig of this size: grow the buffers, fetch what the device already holds
+        out.reserve(ctx, res.n_sig);
+        rc = csvgpu_chr_fetch(ctx, shard, &res, out.sig, out.lab);
+    }
+    check(ctx, rc, "processChromosome");
     st.n_signatures = res.n_sig; st.n_del = res.n_del; st.n_ins = res.n_ins;
     st.depth_sum = res.depth_sum; st.depth_nonzero = res.depth_nonzero; st.mean_chr_cov = res.mean_cov; st.dbscan_min_pts = res.min_pts;
     if (pct > 0.0)
         printMessage(chr + ": Mean chr. cov.: " + std::to_string(res.mean_cov) + " (DBSCAN min. pts.= " + std::to_string(res.min_pts) +
                      ", min. pts. pct.= " + std::to_string(pct) + ")");
-    out.sig.resize(res.n_sig);
-    out.lab.resize(res.n_sig);
     out.n_del = res.n_del; out.n_ins = res.n_ins;
-    check(ctx, csvgpu_chr_fetch(ctx, shard, &res, out.sig.data(), out.lab.data()), "fetch signatures + labels");
     st.ms_device = now_ms() - t0;
 }
 
@@ -102,23 +123,28 @@ void SVCaller::runDeviceChain(const std::string &chr, csv_shard *shard, double e
 // Every CIGAR call has hmm_likelihood == 0, so only the length-ranked branch of the representative choice
 // can run (sv_object.cpp:187-244 of the reference); it is evaluated on the 16-byte signatures and an SVCall
 // (with its strings) is materialised for the chosen member only.
+void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t n_del, uint64_t n_ins, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls)
+{
+    const uint64_t n_sig = n_del + n_ins;
+    chr_sv_calls.clear();
+    if (n_sig < 2) {                                   // mergeSVs returns early (:49-51)
+        for (uint64_t i = 0; i < n_sig; i++) chr_sv_calls.push_back(toSVCall(sig[i], seq));
+        return;
+    }
+    const uint64_t type_n[2] = {n_del, n_ins};
+    uint64_t base = 0;
+    for (int t = 0; t < 2; t++) {
+        if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) chr_sv_calls.push_back(toSVCall(sig[base + i], seq));
+        else mergeSignaturesWithLabels(sig + base, labels + base, type_n[t], seq, chr_sv_calls);
+        base += type_n[t];
+    }
+}
+
 void SVCaller::hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st)
 {
     const double t1 = now_ms();
-    const uint64_t n_sig = in.sig.size();
-    chr_sv_calls.clear();
     printMessage(chr + ": Merging CIGAR...");
-    if (n_sig < 2) {                                   // mergeSVs returns early (:49-51)
-        for (uint64_t i = 0; i < n_sig; i++) chr_sv_calls.push_back(toSVCall(in.sig[i], seq));
-    } else {
-        const uint64_t type_n[2] = {in.n_del, in.n_ins};
-        uint64_t base = 0;
-        for (int t = 0; t < 2; t++) {
-            if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) chr_sv_calls.push_back(toSVCall(in.sig[base + i], seq));
-            else mergeSignaturesWithLabels(in.sig.data() + base, in.lab.data() + base, type_n[t], seq, chr_sv_calls);
-            base += type_n[t];
-        }
-    }
+    mergeOrdered(in.sig, in.lab, in.n_del, in.n_ins, seq, chr_sv_calls);
     st.ms_host_merge = now_ms() - t1;
     printMessage(chr + ": Found " + std::to_string(getSVCount(chr_sv_calls)) + " SV candidates in the CIGAR string");
 }
@@ -137,7 +163,7 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
     const size_t n = shards.size();
     calls.assign(n, {});
     stats.assign(n, ChrStats());
-    std::vector<DeviceOut> slot(2);                       // double buffer between the device thread and the merge thread
+    DeviceOut slot[2];                                    // double buffer between the device thread and the merge thread
     std::mutex mu;
     std::condition_variable cv;
     size_t produced = 0, consumed = 0;                    // shards handed over / merged

@@ -115,13 +115,22 @@ public:
     // signature -> SVCall with the reference's field values (sv_caller.cpp:569-643)
     static SVCall toSVCall(const csv_sig &s, const SeqStore *seq);
     static void mergeSignaturesWithLabels(const csv_sig *sig, const int32_t *labels, uint64_t n, const SeqStore *seq, std::vector<SVCall> &merged);
+    // The host half of processChromosome on its own: ordered signatures (DEL block then INS block) + their labels -> merged calls.
+    static void mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t n_del, uint64_t n_ins, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls);
 
 private:
     csv_ctx *ctx;
-    struct DeviceOut {                       // what the device chain of one shard hands to the host merge
-        std::vector<csv_sig> sig;
-        std::vector<int32_t> lab;
-        uint64_t n_del = 0, n_ins = 0;
+    struct DeviceOut {                       // what the device chain of one shard hands to the host merge: page-locked result buffers
+        csv_ctx *ctx = nullptr;
+        csv_sig *sig = nullptr;
+        int32_t *lab = nullptr;
+        uint64_t cap = 0, n_del = 0, n_ins = 0;
+        DeviceOut() = default;
+        DeviceOut(const DeviceOut &) = delete;
+        DeviceOut &operator=(const DeviceOut &) = delete;
+        ~DeviceOut() { release(); }
+        void release() { if (ctx) { csvgpu_host_free(ctx, sig); csvgpu_host_free(ctx, lab); } sig = nullptr; lab = nullptr; cap = 0; }
+        void reserve(csv_ctx *c, uint64_t n);
     };
     void runDeviceChain(const std::string &chr, csv_shard *shard, double eps, double pct, DeviceOut &out, ChrStats &st);
     static void hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st);

@@ -72,6 +72,28 @@ struct PointMetric {                   // p = points sorted ascending (int order
 
 constexpr int UF_TILE = 256;           // points per workgroup
 constexpr int DB_HALO = 128;           // staged on each side of the tile; windows that reach further read global memory
+constexpr int DB_G = 16;               // lanes that share one point's window (a DPP row)
+constexpr int DB_THREADS = 1024;       // UF_TILE points x DB_G lanes / 4 points per lane group
+constexpr int DB_GROUPS = DB_THREADS / DB_G;
+
+__device__ __forceinline__ int group_sum(int v)
+{
+#pragma unroll
+    for (int d = DB_G / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, DB_G);
+    return v;
+}
+__device__ __forceinline__ int group_max(int v)
+{
+#pragma unroll
+    for (int d = DB_G / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, DB_G));
+    return v;
+}
+__device__ __forceinline__ int group_min(int v)
+{
+#pragma unroll
+    for (int d = DB_G / 2; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, DB_G));
+    return v;
+}
 
 // Elems of positions [t0 - DB_HALO, t0 + UF_TILE + DB_HALO) in LDS
 template <class M>
@@ -89,7 +111,7 @@ template <class M>
 __device__ __forceinline__ Staged<M> stage_tile(const M &m, typename M::Elem *sh, uint64_t t0, uint64_t n)
 {
     const int64_t first = (int64_t)t0 - DB_HALO;
-    for (int k = threadIdx.x; k < UF_TILE + 2 * DB_HALO; k += UF_TILE) {
+    for (int k = threadIdx.x; k < UF_TILE + 2 * DB_HALO; k += blockDim.x) {
         const int64_t idx = first + k;
         if (idx >= 0 && (uint64_t)idx < n) sh[k] = m.load((uint64_t)idx);
     }
@@ -99,28 +121,43 @@ __device__ __forceinline__ Staged<M> stage_tile(const M &m, typename M::Elem *sh
 
 // Two independent point sets can share every launch: positions [0, split) are one set, [split, n) the other (the DEL
 // and INS calls of a chromosome). A window never leaves its own set; cluster ids restart at 0 in the second set.
+// A window holds a few dozen candidates and its loop is a chain of dependent steps, so one thread per point leaves the chip
+// idle (n / 64 waves for n ~ 1e5): DB_G lanes share a point and stride its window together.
 template <class M>
-__global__ void __launch_bounds__(UF_TILE) db_count_kernel(M m, uint64_t n, uint64_t split, int min_pts_imm, const int *__restrict__ d_min_pts,
+__global__ void __launch_bounds__(DB_THREADS) db_count_kernel(M m, uint64_t n, uint64_t split, int min_pts_imm, const int *__restrict__ d_min_pts,
                                 const uint32_t *__restrict__ oid, uint8_t *__restrict__ core, uint32_t *__restrict__ parent,
                                 uint32_t *__restrict__ is_root, unsigned int *__restrict__ ticket)
 {
     __shared__ typename M::Elem sh[UF_TILE + 2 * DB_HALO];
-    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE, i = t0 + threadIdx.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE;
     const Staged<M> at = stage_tile(m, sh, t0, n);
-    if (i == n) { is_root[n] = 0; *ticket = 0; }
-    if (i >= n) return;
-    const uint32_t me = oid ? oid[i] : (uint32_t)i;
-    parent[me] = me;                                   // union-find + root flags start here (no separate init launch)
-    is_root[me] = 0;
+    if (t0 + threadIdx.x == n) { is_root[n] = 0; *ticket = 0; }
     const int min_pts = d_min_pts ? *d_min_pts : min_pts_imm;
-    const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
-    const typename M::Elem mine = at(i);
-    uint64_t lo, hi;
-    m.window(mine, lo, hi);
-    int cnt = 0;
-    for (uint64_t j = i; j < s1; j++) { const typename M::Elem o = at(j); if ((uint64_t)M::key(o) > hi) break; cnt += m.nb(mine, o); }
-    for (uint64_t j = i; j-- > s0;) { const typename M::Elem o = at(j); if ((uint64_t)M::key(o) < lo) break; cnt += m.nb(mine, o); }
-    core[i] = cnt >= min_pts;
+    const uint32_t g = threadIdx.x / DB_G, lane = threadIdx.x % DB_G;
+    for (uint32_t li = g; li < UF_TILE; li += DB_GROUPS) {
+        const uint64_t i = t0 + li;
+        if (i >= n) break;
+        const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
+        const typename M::Elem mine = at(i);
+        uint64_t lo, hi;
+        m.window(mine, lo, hi);
+        int cnt = 0;
+        for (uint64_t j0 = i; j0 < s1 && (uint64_t)M::key(at(j0)) <= hi; j0 += DB_G) {        // j0 == i: the point itself
+            const uint64_t j = j0 + lane;
+            if (j < s1) { const typename M::Elem o = at(j); if ((uint64_t)M::key(o) <= hi) cnt += m.nb(mine, o); }
+        }
+        for (uint64_t b0 = i; b0 > s0 && (uint64_t)M::key(at(b0 - 1)) >= lo; b0 = b0 > DB_G ? b0 - DB_G : 0) {
+            if (b0 >= (uint64_t)lane + 1 && b0 - 1 - lane >= s0) { const typename M::Elem o = at(b0 - 1 - lane); if ((uint64_t)M::key(o) >= lo) cnt += m.nb(mine, o); }
+            if (b0 <= DB_G) break;
+        }
+        cnt = group_sum(cnt);
+        if (lane == 0) {
+            const uint32_t me = oid ? oid[i] : (uint32_t)i;
+            parent[me] = me;                           // union-find + root flags start here (no separate init launch)
+            is_root[me] = 0;
+            core[i] = cnt >= min_pts;
+        }
+    }
 }
 
 __device__ __forceinline__ uint32_t uf_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -164,30 +201,36 @@ __device__ __forceinline__ uint32_t lds_find(uint32_t *lpar, uint32_t x)
 // Pairs with both ends in one tile of UF_TILE consecutive positions: union-find in LDS (a cluster's members are neighbours in
 // the sorted order, so this is nearly every pair), then each core point's parent is written flat: parent[me] = its tile root.
 template <class M>
-__global__ void __launch_bounds__(UF_TILE) db_union_local_kernel(M m, uint64_t n, uint64_t split, const uint8_t *__restrict__ core,
-                                                                 const uint32_t *__restrict__ oid, uint32_t *__restrict__ parent)
+__global__ void __launch_bounds__(DB_THREADS) db_union_local_kernel(M m, uint64_t n, uint64_t split, const uint8_t *__restrict__ core,
+                                                                    const uint32_t *__restrict__ oid, uint32_t *__restrict__ parent)
 {
     __shared__ uint32_t lpar[UF_TILE], loid[UF_TILE];
     __shared__ typename M::Elem sh[UF_TILE];
     __shared__ uint8_t lcore[UF_TILE];
-    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE, i = t0 + threadIdx.x;
-    const uint32_t li = threadIdx.x;
-    lpar[li] = li;
-    loid[li] = i < n ? (oid ? oid[i] : (uint32_t)i) : NONE;
-    lcore[li] = i < n ? core[i] : 0;
-    if (i < n) sh[li] = m.load(i);
+    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE;
+    if (threadIdx.x < UF_TILE) {
+        const uint32_t li = threadIdx.x;
+        const uint64_t i = t0 + li;
+        lpar[li] = li;
+        loid[li] = i < n ? (oid ? oid[i] : (uint32_t)i) : NONE;
+        lcore[li] = i < n ? core[i] : 0;
+        if (i < n) sh[li] = m.load(i);
+    }
     __syncthreads();
-    const bool active = lcore[li] != 0;
-    if (active) {
+    const uint32_t g = threadIdx.x / DB_G, lane = threadIdx.x % DB_G;
+    for (uint32_t li = g; li < UF_TILE; li += DB_GROUPS) {
+        if (!lcore[li]) continue;
+        const uint64_t i = t0 + li;
         const typename M::Elem mine = sh[li];
         uint64_t lo, hi;
         m.window(mine, lo, hi);
         const uint64_t s1 = i < split ? split : n;
         const uint32_t l_end = (uint32_t)(min(t0 + UF_TILE, s1) - t0);
-        for (uint32_t lj = li + 1; lj < l_end; lj++) {
+        for (uint32_t j0 = li + 1; j0 < l_end && (uint64_t)M::key(sh[j0]) <= hi; j0 += DB_G) {
+            const uint32_t lj = j0 + lane;
+            if (lj >= l_end) continue;
             const typename M::Elem o = sh[lj];
-            if ((uint64_t)M::key(o) > hi) break;
-            if (!lcore[lj] || !m.nb(mine, o)) continue;
+            if ((uint64_t)M::key(o) > hi || !lcore[lj] || !m.nb(mine, o)) continue;
             uint32_t a = li, b = lj;
             for (;;) {
                 a = lds_find(lpar, a);
@@ -199,7 +242,7 @@ __global__ void __launch_bounds__(UF_TILE) db_union_local_kernel(M m, uint64_t n
         }
     }
     __syncthreads();
-    if (active) parent[loid[li]] = loid[lds_find(lpar, li)];
+    if (threadIdx.x < UF_TILE && lcore[threadIdx.x]) parent[loid[threadIdx.x]] = loid[lds_find(lpar, threadIdx.x)];
 }
 
 // Pairs whose later end lies beyond the tile of the earlier one.
@@ -224,7 +267,7 @@ __global__ void db_union_cross_kernel(M m, uint64_t n, uint64_t split, const uin
         if ((uint64_t)M::key(o) > hi) break;
         if (!core[j] || !m.nb(mine, o)) continue;
         const uint32_t oj = oid ? oid[j] : (uint32_t)j;
-        const uint32_t pj = uf_load(&parent[oj]);
+        const uint32_t pj = parent[oj];                   // the local pass's value is enough to tell tile components apart (a plain, cached load)
         if (pj == last_parent) continue;
         last_parent = pj;
         uf_union(parent, me, oj);
@@ -308,46 +351,47 @@ struct TileCid {
 };
 
 template <class M, class C>
-__global__ void __launch_bounds__(UF_TILE) db_label_kernel(M m, uint64_t n, uint64_t split, const uint32_t *__restrict__ oid, const uint32_t *__restrict__ root_of,
+__global__ void __launch_bounds__(DB_THREADS) db_label_kernel(M m, uint64_t n, uint64_t split, const uint32_t *__restrict__ oid, const uint32_t *__restrict__ root_of,
                                 C cid_raw, int32_t *__restrict__ labels)
 {
     __shared__ typename M::Elem sh[UF_TILE + 2 * DB_HALO];
-    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE, i = t0 + threadIdx.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE;
     const Staged<M> at = stage_tile(m, sh, t0, n);
-    if (i >= n) return;
-    const uint32_t me = oid ? oid[i] : (uint32_t)i;
-    const uint32_t r = root_of[i];
-    // ids of the second set restart at 0: subtract the number of roots of the first set (only used with oid == nullptr,
-    // where original index == position, so cid_raw(split) is that count)
-    const uint32_t id0 = (i >= split && split < n) ? cid_raw((uint32_t)split) : 0u;
-    const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
-    struct { C c; uint32_t off; __device__ uint32_t operator[](uint32_t k) const { return c(k) - off; } } cid{cid_raw, id0};
-    if (r != NONE) { labels[me] = (int32_t)cid[r]; return; }
-    const typename M::Elem mine = at(i);
-    uint64_t lo, hi;
-    m.window(mine, lo, hi);
-    int32_t max_start = -1, min_core = INT32_MAX;
-    for (uint64_t j = i + 1; j < s1; j++) {
-        const typename M::Elem o = at(j);
-        if ((uint64_t)M::key(o) > hi) break;
-        if (!m.nb(mine, o)) continue;
-        const uint32_t rj = root_of[j];
-        if (rj != NONE) {
+    const uint32_t g = threadIdx.x / DB_G, lane = threadIdx.x % DB_G;
+    for (uint32_t li = g; li < UF_TILE; li += DB_GROUPS) {
+        const uint64_t i = t0 + li;
+        if (i >= n) break;
+        const uint32_t me = oid ? oid[i] : (uint32_t)i;
+        const uint32_t r = root_of[i];
+        // ids of the second set restart at 0: subtract the number of roots of the first set (only used with oid == nullptr,
+        // where original index == position, so cid_raw(split) is that count)
+        const uint32_t id0 = (i >= split && split < n) ? cid_raw((uint32_t)split) : 0u;
+        const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
+        struct { C c; uint32_t off; __device__ uint32_t operator[](uint32_t k) const { return c(k) - off; } } cid{cid_raw, id0};
+        if (r != NONE) { if (lane == 0) labels[me] = (int32_t)cid[r]; continue; }
+        const typename M::Elem mine = at(i);
+        uint64_t lo, hi;
+        m.window(mine, lo, hi);
+        int32_t max_start = -1, min_core = INT32_MAX;
+        auto visit = [&](uint64_t j, const typename M::Elem &o) {
+            if (!m.nb(mine, o)) return;
+            const uint32_t rj = root_of[j];
+            if (rj == NONE) return;
             const int32_t c = (int32_t)cid[rj];
             if (rj == (oid ? oid[j] : (uint32_t)j)) max_start = max(max_start, c); else min_core = min(min_core, c);
+        };
+        for (uint64_t j0 = i + 1; j0 < s1 && (uint64_t)M::key(at(j0)) <= hi; j0 += DB_G) {
+            const uint64_t j = j0 + lane;
+            if (j < s1) { const typename M::Elem o = at(j); if ((uint64_t)M::key(o) <= hi) visit(j, o); }
         }
-    }
-    for (uint64_t j = i; j-- > s0;) {
-        const typename M::Elem o = at(j);
-        if ((uint64_t)M::key(o) < lo) break;
-        if (!m.nb(mine, o)) continue;
-        const uint32_t rj = root_of[j];
-        if (rj != NONE) {
-            const int32_t c = (int32_t)cid[rj];
-            if (rj == (oid ? oid[j] : (uint32_t)j)) max_start = max(max_start, c); else min_core = min(min_core, c);
+        for (uint64_t b0 = i; b0 > s0 && (uint64_t)M::key(at(b0 - 1)) >= lo; b0 = b0 > DB_G ? b0 - DB_G : 0) {
+            if (b0 >= (uint64_t)lane + 1 && b0 - 1 - lane >= s0) { const typename M::Elem o = at(b0 - 1 - lane); if ((uint64_t)M::key(o) >= lo) visit(b0 - 1 - lane, o); }
+            if (b0 <= DB_G) break;
         }
+        max_start = group_max(max_start);
+        min_core = group_min(min_core);
+        if (lane == 0) labels[me] = max_start >= 0 ? max_start : (min_core != INT32_MAX ? min_core : -2);
     }
-    labels[me] = max_start >= 0 ? max_start : (min_core != INT32_MAX ? min_core : -2);
 }
 
 // tmp: core u8[n] | parent u32[n] | root_of u32[n] | is_root/cid u32[n+1] | scan tmp
@@ -373,16 +417,17 @@ static void run_dbscan(hipStream_t s, M m, const uint32_t *oid, uint64_t n, uint
     uint32_t *tile_prefix = (uint32_t *)p; p += align_up(((uint64_t)n_tiles + 1) * 4, 256);
     unsigned int *ticket = (unsigned int *)p;
     const dim3 grid((unsigned)((n + 255) / 256)), grid1((unsigned)((n + 1 + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(db_count_kernel<M>, grid1, blk, 0, s, m, n, split, min_pts, d_min_pts, oid, core, parent, cid, ticket);
-    hipLaunchKernelGGL(db_union_local_kernel<M>, grid, dim3(UF_TILE), 0, s, m, n, split, core, oid, parent);
+    const dim3 wide(DB_THREADS);
+    hipLaunchKernelGGL(db_count_kernel<M>, grid1, wide, 0, s, m, n, split, min_pts, d_min_pts, oid, core, parent, cid, ticket);
+    hipLaunchKernelGGL(db_union_local_kernel<M>, grid, wide, 0, s, m, n, split, core, oid, parent);
     hipLaunchKernelGGL(db_union_cross_kernel<M>, grid, blk, 0, s, m, n, split, core, oid, parent);
     if (!oid) {
         hipLaunchKernelGGL(db_roots_rank_kernel, dim3(n_tiles), dim3(UF_TILE), 0, s, n, core, parent, root_of, cid, tile_count, tile_prefix, ticket, n_tiles);
-        hipLaunchKernelGGL((db_label_kernel<M, TileCid>), grid, blk, 0, s, m, n, split, oid, root_of, TileCid{tile_prefix, cid}, labels);
+        hipLaunchKernelGGL((db_label_kernel<M, TileCid>), grid, wide, 0, s, m, n, split, oid, root_of, TileCid{tile_prefix, cid}, labels);
     } else {
         hipLaunchKernelGGL(db_roots_kernel, grid, blk, 0, s, n, core, oid, parent, root_of, cid);
         launch_exclusive_sum_u32(s, cid, n + 1, es_tmp);
-        hipLaunchKernelGGL((db_label_kernel<M, ScanCid>), grid, blk, 0, s, m, n, split, oid, root_of, ScanCid{cid}, labels);
+        hipLaunchKernelGGL((db_label_kernel<M, ScanCid>), grid, wide, 0, s, m, n, split, oid, root_of, ScanCid{cid}, labels);
     }
 }
 

@@ -227,6 +227,19 @@ int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, 
  * label_ins) of the last csvgpu_chr_pipeline_dev() on `shard` to host memory with one synchronisation. */
 int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *shard, const csv_chr_result *result, csv_sig *host_sig, int32_t *host_labels);
 
+/* csvgpu_chr_pipeline_dev + csvgpu_chr_fetch in one call with a single final synchronisation: when the chromosome's
+ * n_sig <= capacity the signatures and labels are copied to host_sig / host_labels behind the last kernel and the scalars
+ * ride in the same wait. With n_sig > capacity nothing is copied and CSV_ECAPACITY is returned; *result is valid (n_sig
+ * says how much room is needed) and csvgpu_chr_fetch() can still fetch. Pass buffers from csvgpu_host_alloc() so that the
+ * copies are true asynchronous DMA. */
+int csvgpu_chr_pipeline_fetch(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
+                              csv_chr_result *result, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity);
+
+/* Page-locked host memory for result buffers (hipHostMalloc); NULL on failure. Freed blocks are kept by the context for reuse
+ * and released by csvgpu_destroy(), which also releases blocks never freed: do not use them after the context is gone. */
+void *csvgpu_host_alloc(csv_ctx *ctx, size_t bytes);
+void csvgpu_host_free(csv_ctx *ctx, void *p);
+
 /* The alignment intervals that the last csvgpu_chr_pipeline_dev() computed for every record of `shard`, copied to host. */
 int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *shard, int32_t *ref_end, int32_t *q_start, int32_t *q_end);
 
