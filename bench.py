@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-file", action="store_true", help="skip the BAM-staged from-file measurement")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after the other (step latency)")
+    ap.add_argument("--lanes", type=int, default=2, help="chromosomes in flight per GPU (contexts with one stream each, gated scan + depth phases)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0, help="fraction of the shard's reads given to the CPU baseline")
     args = ap.parse_args()
 
@@ -83,6 +84,18 @@ def main():
     shard = ctx.upload(reads, depth_len)
     ctx.synchronize()
     t_upload = time.time() - t0
+    # further lanes: their own context (stream, arenas) and their own resident copy of the contig, as a second chromosome would be
+    n_lanes = 1 if args.no_pipeline else max(1, args.lanes)
+    lane_ctx, lane_shard = [ctx], [shard]
+    gate = cs.Gate() if n_lanes > 1 else None
+    for _ in range(1, n_lanes):
+        c = cs.Context(dev.index)
+        lane_ctx.append(c)
+        lane_shard.append(c.upload(reads, depth_len))
+        c.synchronize()
+    if gate:
+        for c in lane_ctx:
+            c.set_gate(gate)
     h2d_bytes = reads.cigar.nbytes + reads.pos.nbytes + reads.flag.nbytes + reads.mapq.nbytes + reads.cigar_off.nbytes
 
     from contextsv_amd import parallel
@@ -94,6 +107,9 @@ def main():
             calls = st = None
             for _ in range(n_steps):
                 calls, tags, st = host.process_resident_chromosome(ctx, shard, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
+        elif n_lanes > 1:
+            steps = [n_steps // n_lanes + (1 if l < n_steps % n_lanes else 0) for l in range(n_lanes)]
+            calls, st, ms, tot = host.process_resident_lanes(lane_ctx, lane_shard, steps, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
         else:
             calls, tags, st, ms, tot = host.process_resident_pipelined(ctx, shard, n_steps, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
         if world > 1:
@@ -106,19 +122,25 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.synchronize()
+        for c in lane_ctx:
+            c.synchronize()
 
     if args.warmup:
         job(args.warmup)
-    ctx.timing_enable(True)
-    ctx.timing_reset()
+    for c in lane_ctx:
+        c.timing_enable(True)
+        c.timing_reset()
     barrier()
     t0 = time.perf_counter()
     calls, st = job(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    timing = ctx.timing()
-    ctx.timing_enable(False)
+    timing = {}
+    for c in lane_ctx:                                   # kernel time and launch count summed over the lanes
+        for k, (ms, n) in c.timing().items():
+            a = timing.get(k, (0.0, 0))
+            timing[k] = (a[0] + ms, a[1] + n)
+        c.timing_enable(False)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(reads.n_reads), float(st.n_signatures), float(reads.n_cigar)], dtype=torch.float64, device=dev)
@@ -166,7 +188,7 @@ def main():
                        "reads_per_gpu": int(reads.n_reads), "cigar_ops_per_gpu": int(reads.n_cigar),
                        "signatures_per_gpu": int(st.n_signatures), "merged_calls_per_gpu": int(st.n_calls),
                        "eps": args.eps, "min_pts_pct": args.min_pts_pct, "min_pts": int(st.min_pts), "parallelism": f"chromosome-shard x{world}",
-                       "pipelined": not args.no_pipeline},
+                       "pipelined": not args.no_pipeline, "lanes": n_lanes},
             "signatures_clustered_per_s": sigs_all * args.steps / elapsed,
             "cigar_ops_per_s": ops_all * args.steps / elapsed,
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kern.items() if v > 0},
@@ -186,8 +208,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(reads, depth_len, args, st)
         print(json.dumps(out), flush=True)
 
+    for sh_, c in zip(lane_shard[1:], lane_ctx[1:]):
+        sh_.free()
+        c.close()
     shard.free()
     ctx.close()
+    if gate:
+        gate.close()
     syn.free()
     if world > 1:
         dist.barrier()

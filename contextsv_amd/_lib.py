@@ -70,6 +70,9 @@ ABI = {
     "csvgpu_shard_free": (None, [_P, _P]),
     "csvgpu_chr_pipeline_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.POINTER(csv_chr_result)]),
     "csvgpu_chr_pipeline_fetch": (C.c_int, [_P, _P, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.POINTER(csv_chr_result), _P, _P, C.c_uint64]),
+    "csvgpu_gate_create": (_P, []),
+    "csvgpu_gate_destroy": (None, [_P]),
+    "csvgpu_set_gate": (C.c_int, [_P, _P]),
     "csvgpu_host_alloc": (_P, [_P, C.c_size_t]),
     "csvgpu_host_free": (None, [_P, _P]),
     "csvgpu_aln_intervals_resident": (C.c_int, [_P, _P, _P, _P, _P]),

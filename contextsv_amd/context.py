@@ -61,6 +61,21 @@ class Reads:
         return Reads(np.asarray(pos), np.asarray(flag), np.asarray(mapq), off, np.asarray(words, dtype=np.uint32))
 
 
+class Gate:
+    """csv_gate: several Contexts on one GPU take turns with their bandwidth-bound phases (csvgpu_gate_*)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.h = self.lib.csvgpu_gate_create()
+        if not self.h:
+            raise CsvError(_lib.CSV_ENOMEM, "csvgpu_gate_create failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.csvgpu_gate_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """One csv_ctx (= one GPU). `stream` may be an existing hipStream_t handle (e.g. torch's)."""
 
@@ -75,6 +90,9 @@ class Context:
         if getattr(self, "h", None):
             self.lib.csvgpu_destroy(self.h)
             self.h = None
+
+    def set_gate(self, gate: "Gate | None"):
+        self._check(self.lib.csvgpu_set_gate(self.h, gate.h if gate is not None else None))
 
     __del__ = close
 

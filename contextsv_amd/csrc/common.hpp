@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,12 @@ struct Arena {                     // grow-only bump allocator over one device b
 
 }  // namespace csv
 
+// turn-taking of the bandwidth-bound phases of several contexts on one device (csvgpu_gate_*)
+struct csv_gate {
+    std::mutex mu;
+    hipEvent_t last = nullptr;          // recorded behind the most recent scan + depth phase of any attached context
+};
+
 struct csv_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
@@ -52,12 +59,14 @@ struct csv_ctx {
     int          n_cu = 256;
     // csvgpu_host_alloc / csvgpu_host_free: page-locking is slow (hundreds of microseconds), so freed blocks are kept for reuse
     std::vector<std::pair<void *, size_t>> host_live, host_pool;
+    csv_gate    *gate = nullptr;
 };
 
 struct csv_shard {
     csv_reads d;                   // device pointers
     uint32_t  depth_len = 0;
     bool      owned = false;       // true: arrays hipMalloc'd by csvgpu_shard_upload
+    int       unsorted = -1;       // pos[] not non-decreasing: 1 / 0, or -1 while unknown (wrapped device arrays before their first scan)
     // per-read side arrays + per-chromosome outputs (device, owned by the shard)
     int32_t  *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr, *pmax_end = nullptr;
     uint32_t *ckpt = nullptr;      // per-256-word reference checkpoints (scan -> depth)

@@ -711,6 +711,8 @@ csv_shard *csvgpu_shard_upload(csv_ctx *ctx, const csv_reads *r, uint32_t depth_
     ok &= hipMalloc((void **)&sh->d.cigar, m * 4 + 16) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); ctx->err = "hipMalloc failed (shard upload)"; shard_release(sh); return nullptr; }
     hipStream_t s = ctx->stream;
+    sh->unsorted = 0;                                    // known before the first scan: lets the pipeline queue the depth pass without waiting
+    for (uint64_t i = 1; i < n; i++) if (r->pos[i] < r->pos[i - 1]) { sh->unsorted = 1; break; }
     bool cp = true;
     if (n) {
         cp &= hipMemcpyAsync((void *)sh->d.pos, r->pos, n * 4, hipMemcpyHostToDevice, s) == hipSuccess;
@@ -837,6 +839,22 @@ int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t by
     return CSV_OK;
 }
 
+csv_gate *csvgpu_gate_create(void) { return new (std::nothrow) csv_gate(); }
+
+void csvgpu_gate_destroy(csv_gate *gate)
+{
+    if (!gate) return;
+    if (gate->last) (void)hipEventDestroy(gate->last);
+    delete gate;
+}
+
+int csvgpu_set_gate(csv_ctx *ctx, csv_gate *gate)
+{
+    if (!ctx) return CSV_EINVAL;
+    ctx->gate = gate;
+    return CSV_OK;
+}
+
 void *csvgpu_host_alloc(csv_ctx *ctx, size_t bytes)
 {
     if (!ctx || !bytes) return nullptr;
@@ -895,17 +913,51 @@ static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t
     ScanCounters *cnt = (ScanCounters *)sh->counters;
     ScanCounters h;
     int rc;
+    // The depth pass does not depend on the signature count, so when the shard's sortedness is already known it is queued behind
+    // the scan BEFORE the host waits for the counters: the device works through it while the host wakes up, sizes the ordering
+    // and clustering launches and queues them, instead of idling across the round trip.
+    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads, sh->depth_len)))) return rc;
+    bool depth_queued = false;
     for (int attempt = 0;; attempt++) {
         CSV_HIP(ctx, hipMemsetAsync(cnt, 0, kCntBytes, s));
+        // with a gate: this context's scan starts behind the previous holder's depth pass, and hands the turn on behind its own
+        csv_gate *gate = sh->unsorted >= 0 ? ctx->gate : nullptr;
+        std::unique_lock<std::mutex> turn;
+        if (gate) {
+            turn = std::unique_lock<std::mutex>(gate->mu);
+            if (gate->last) CSV_HIP(ctx, hipStreamWaitEvent(s, gate->last, 0));
+        }
         {
             TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
             launch_cigar_scan(s, ctx->n_cu, sh->d, sh->depth_len, min_oplen, min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
                               sh->q_start, sh->q_end, sh->ckpt, cnt);
         }
         bucket_prepass(ctx, sh->sig_raw, sh->sig_cap, sh->depth_len, true, cnt);
-        if ((rc = read_counters(ctx, cnt, h))) return rc;                 // the one mid-pipeline host sync
+        depth_queued = false;
+        if (sh->unsorted >= 0) {
+            if ((rc = ensure_pinned(ctx, 4096))) return rc;
+            CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, s));
+            hipEvent_t got = get_event(ctx);
+            CSV_HIP(ctx, hipEventRecord(got, s));
+            ctx->work.used = 0;
+            if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
+            launch_min_pts(s, cnt, min_pts_pct);
+            depth_queued = true;
+            if (gate) {
+                if (!gate->last) CSV_HIP(ctx, hipEventCreateWithFlags(&gate->last, hipEventDisableTiming));
+                CSV_HIP(ctx, hipEventRecord(gate->last, s));
+                turn.unlock();
+            }
+            CSV_HIP(ctx, hipEventSynchronize(got));
+            ctx->event_pool.push_back(got);
+            memcpy(&h, ctx->pinned, sizeof(ScanCounters));
+        } else {
+            if ((rc = read_counters(ctx, cnt, h))) return rc;             // first scan of wrapped arrays: wait, then decide
+            sh->unsorted = h.unsorted != 0;
+        }
         if (h.n_sig <= sh->sig_cap) break;
         if (attempt) { ctx->err = "pipeline: signature buffer overflow twice"; return CSV_ENOMEM; }
+        CSV_HIP(ctx, hipStreamSynchronize(s));                            // the queued depth pass reads what the re-run scan rewrites
         CSV_HIP(ctx, hipFree(sh->sig_raw));
         sh->sig_raw = nullptr; sh->sig_cap = h.n_sig + h.n_sig / 8 + 1024;
         CSV_HIP(ctx, hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)));
@@ -931,10 +983,12 @@ static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t
     void *db_tmp = arena_alloc(sa, dbscan_tmp_bytes(n_big));
     if (!sig_sorted || !st || !en || !labels || !ws_ok || !db_tmp) { ctx->err = "shard scratch exhausted"; return CSV_ENOMEM; }
 
-    // depth map + mean coverage + min_pts (device scalar)
-    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads, sh->depth_len)))) return rc;
-    if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, h.unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
-    launch_min_pts(s, cnt, min_pts_pct);
+    // depth map + mean coverage + min_pts (device scalar), unless already queued above
+    if (!depth_queued) {
+        ctx->work.used = 0;
+        if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
+        launch_min_pts(s, cnt, min_pts_pct);
+    }
 
     // ordering: DEL calls then INS calls, each in chr_sv_calls order
     order_signatures(ctx, sh->sig_raw, n, sh->depth_len, h.max_start, max_bucket, cnt, true, w, sig_sorted, st, en);

@@ -222,6 +222,35 @@ int csvhost_process_resident_pipelined(csv_ctx *ctx, csv_shard *shard, uint64_t 
     })
 }
 
+// n_lanes contexts of one GPU, lane l runs steps[l] passes over its own resident shard concurrently with the others.
+// Returns lane 0's last merged calls + stats averaged over every step of every lane; ms_total = wall time of the whole job.
+int csvhost_process_resident_lanes(int n_lanes, csv_ctx *const *ctxs, csv_shard *const *shards, const uint64_t *steps, double eps, double min_pts_pct,
+                                   csvhost_call *out, uint64_t cap, csvhost_chr_stats *st, double *ms_total, uint64_t *total_calls)
+{
+    GUARD({
+        std::vector<SVCaller::Lane> lanes((size_t)n_lanes);
+        for (int l = 0; l < n_lanes; l++) { lanes[l].ctx = ctxs[l]; lanes[l].shards.assign(steps[l], shards[l]); }
+        std::vector<std::vector<std::vector<SVCall>>> calls;
+        std::vector<std::vector<ChrStats>> stats;
+        const auto t0 = std::chrono::steady_clock::now();
+        SVCaller::processResidentLanes(lanes, nullptr, eps, min_pts_pct, calls, stats);
+        *ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        uint64_t tot = 0, n_steps = 0;
+        double dev = 0, hm = 0;
+        for (auto &lane : calls) for (auto &c : lane) tot += c.size();
+        for (auto &lane : stats) for (auto &x : lane) { dev += x.ms_device; hm += x.ms_host_merge; n_steps++; }
+        *total_calls = tot;
+        if (n_steps && !stats[0].empty()) {
+            const ChrStats &cs = stats[0].back();
+            const std::vector<SVCall> &last = calls[0].back();
+            st->n_signatures = cs.n_signatures; st->n_del = cs.n_del; st->n_ins = cs.n_ins; st->depth_sum = cs.depth_sum;
+            st->depth_nonzero = cs.depth_nonzero; st->min_pts = cs.dbscan_min_pts; st->mean_cov = cs.mean_chr_cov;
+            st->ms_device = dev / n_steps; st->ms_host_merge = hm / n_steps; st->n_calls = last.size();
+            for (size_t i = 0; i < last.size() && i < cap; i++) out[i] = to_pod(last[i]);
+        }
+    })
+}
+
 // ---- split-read signatures (findSplitSVSignatures mirror) ---------------------------------------
 struct csvhost_split_call { uint32_t start, end; int32_t sv_type, cluster_size, aln_offset; uint32_t aln_flags; int32_t tid; };
 

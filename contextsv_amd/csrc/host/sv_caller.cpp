@@ -196,6 +196,25 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
     if (worker_err) std::rethrow_exception(worker_err);
 }
 
+void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double eps, double pct,
+                                    std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats)
+{
+    calls.assign(lanes.size(), {});
+    stats.assign(lanes.size(), {});
+    std::vector<std::exception_ptr> errs(lanes.size());
+    std::vector<std::thread> threads;
+    for (size_t l = 0; l < lanes.size(); l++) {
+        threads.emplace_back([&, l] {
+            try {
+                SVCaller caller(lanes[l].ctx);
+                caller.processResidentChromosomesPipelined(lanes[l].shards, seq, eps, pct, calls[l], stats[l]);
+            } catch (...) { errs[l] = std::current_exception(); }
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (auto &e : errs) if (e) std::rethrow_exception(e);
+}
+
 void SVCaller::processChromosome(const std::string &chr, const csv_reads &reads, const SeqStore *seq, uint32_t depth_len, double eps,
                                  double pct, std::vector<SVCall> &chr_sv_calls, ChrStats &stats, csv_shard **keep_shard)
 {

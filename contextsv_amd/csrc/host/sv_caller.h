@@ -95,6 +95,12 @@ public:
                                              double dbscan_min_pts_pct, std::vector<std::vector<SVCall>> &calls,
                                              std::vector<ChrStats> &stats);
 
+    // Several chromosomes in flight on one GPU: every lane is a context of its own (own stream; attach one csv_gate to all of them so
+    // that their scan + depth phases take turns) and runs processResidentChromosomesPipelined on its shards in its own pair of threads.
+    struct Lane { csv_ctx *ctx; std::vector<csv_shard *> shards; };
+    static void processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double dbscan_epsilon, double dbscan_min_pts_pct,
+                                     std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats);
+
     // Pass ordering of SVCaller::run (sv_caller.cpp:747-946) over in-memory contigs: depth + CIGAR pass + CIGAR merge per
     // contig -> CIGAR copy-number predictions -> split-read signatures -> their copy-number predictions ->
     // mergeSVs(0.1, 2, keep_noise) on the split calls -> concatenation -> final mergeSVs(0.1, 2, keep_noise).

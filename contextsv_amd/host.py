@@ -107,6 +107,8 @@ def load() -> C.CDLL:
     lib.csvhost_pfb_path.argtypes = [C.c_char_p, C.c_char_p, _P, C.c_uint64]
     lib.csvhost_gnomad_contig.restype = C.c_int64
     lib.csvhost_gnomad_contig.argtypes = [C.c_char_p, C.c_char_p, _P, C.c_uint64]
+    lib.csvhost_process_resident_lanes.argtypes = [C.c_int, _P, _P, _P, C.c_double, C.c_double, _P, C.c_uint64, C.POINTER(chr_stats),
+                                                   C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -231,6 +233,21 @@ def process_resident_pipelined(ctx: Context, shard: Shard, n_steps: int, eps: fl
                                                      tag.ctypes.data, capacity, C.byref(st), C.byref(ms), C.byref(tot)))
     n = min(st.n_calls, capacity)
     return out[:n].copy(), tag[:n].copy(), st, ms.value, tot.value
+
+
+def process_resident_lanes(ctxs, shards, steps, eps: float, min_pts_pct: float, capacity: int = 1 << 20):
+    """Several contexts of one GPU, lane l doing steps[l] pipelined passes over shards[l] at the same time (attach one Gate to all
+    contexts first). -> (lane 0's last merged calls, stats averaged over all steps, wall ms, total merged calls)."""
+    n = len(ctxs)
+    cp = (C.c_void_p * n)(*[c.h for c in ctxs])
+    sp = (C.c_void_p * n)(*[s.h for s in shards])
+    st_n = np.asarray(steps, np.uint64)
+    out = np.zeros(capacity, CALL_DTYPE)
+    st = chr_stats()
+    ms, tot = C.c_double(0), C.c_uint64(0)
+    _check(load().csvhost_process_resident_lanes(n, cp, sp, st_n.ctypes.data, eps, min_pts_pct, out.ctypes.data, capacity, C.byref(st), C.byref(ms),
+                                                 C.byref(tot)))
+    return out[: min(st.n_calls, capacity)].copy(), st, ms.value, tot.value
 
 
 def _snp_arrays(snps):

@@ -235,6 +235,16 @@ int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *shard, const csv_chr_result *resul
 int csvgpu_chr_pipeline_fetch(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
                               csv_chr_result *result, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity);
 
+/* Several contexts on one GPU (one per host thread, each with its own stream) keep several chromosomes in flight. A gate makes
+ * their bandwidth-bound phases (CIGAR scan + depth pass) take turns on the device — ordered with events, no host blocking — while
+ * the latency-bound tail of one chromosome (ordering, clustering, copies, host wake-ups) overlaps the scan of the next. The
+ * reference gets its overlap from a thread pool over chromosomes (sv_caller.cpp:827-863); this is the device-side counterpart.
+ * Attach the same gate to every context of the GPU before running pipelines concurrently; detach with gate == NULL. */
+typedef struct csv_gate csv_gate;
+csv_gate *csvgpu_gate_create(void);
+void csvgpu_gate_destroy(csv_gate *gate);                 /* after every attached context is destroyed or detached */
+int csvgpu_set_gate(csv_ctx *ctx, csv_gate *gate);
+
 /* Page-locked host memory for result buffers (hipHostMalloc); NULL on failure. Freed blocks are kept by the context for reuse
  * and released by csvgpu_destroy(), which also releases blocks never freed: do not use them after the context is gone. */
 void *csvgpu_host_alloc(csv_ctx *ctx, size_t bytes);

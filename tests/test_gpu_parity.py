@@ -228,3 +228,27 @@ def test_ordering_with_heavy_ties(ctx, oracle, n_reads, n_pos):
         assert res.n_sig == 3 * n_reads
     finally:
         sh.free()
+
+
+def test_pipeline_regrows_signature_buffer(ctx, oracle):
+    """More signatures than the shard's initial buffer (max(2^18, 2 x reads)): the pipeline re-runs the scan into a larger one —
+    with the depth pass already queued behind the first attempt — and the results are still the oracle's."""
+    M, D = 0, 2
+    n_reads, per = 4500, 64
+    pos = np.sort(np.random.default_rng(3).integers(0, 150_000, n_reads))
+    cig = [[op for k in range(per) for op in ((M, 90 + (r + k) % 7), (D, 50 + (r * 7 + k) % 40))] + [(M, 50)] for r in range(n_reads)]
+    reads = Reads.from_cigar_lists(pos, np.zeros(n_reads, np.uint16), np.full(n_reads, 60, np.uint8), cig)
+    depth_len = 170_000
+    sh = ctx.upload(reads, depth_len)
+    try:
+        res = sh.pipeline(eps=0.1, min_pts_pct=0.1)
+        assert res.n_sig == n_reads * per > (1 << 18)
+        out = sh.fetch(res, want_depth=True)
+        sig = oracle.cigar_scan(reads, depth_len)
+        _same_sigs(out["sig_del"], sig)
+        od, os_, onz = oracle.depth(reads, depth_len)
+        assert np.array_equal(out["depth"], od) and (res.depth_sum, res.depth_nonzero) == (os_, onz)
+        res2 = sh.pipeline(eps=0.1, min_pts_pct=0.1)             # second run: buffer already large enough
+        assert (res2.n_sig, res2.depth_sum, res2.min_pts) == (res.n_sig, res.depth_sum, res.min_pts)
+    finally:
+        sh.free()
