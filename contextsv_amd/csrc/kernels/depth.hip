@@ -239,43 +239,54 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         }
         __syncthreads();
         const uint32_t n_items = wl_n;
+        const int32_t TW = (int32_t)(T1 - T0);                                      // tile width in positions
         for (uint32_t it = depth_grab(&next_item, lane); it < n_items; it = depth_grab(&next_item, lane)) {
             const uint64_t chunk0 = wl_chunk[it];
             const int32_t c0rel = wl_c0rel[it];
             const uint32_t nrem = wl_nrem[it];
-            const uint64_t p1 = wl_p1[it];
-            uint64_t ref_carry = wl_carry[it];
+            // Positions are kept relative to the tile's left edge in 32-bit signed arithmetic (coordinates and run lengths are
+            // below 2^31, the BAM limit): a run [rel, rel + len) clips to [max(rel,0), min(rel+len, TW)) with one max and one min,
+            // and a run with no aligned bases (len masked to 0) clips to nothing, so no separate op test is needed.
+            int32_t base_rel = (int32_t)(wl_p1[it] + wl_carry[it] - (uint32_t)T0);  // wave-uniform: first staged word of the chunk
             uint32_t w[4], w1[4];
-            depth_load4(cigar, n_cigar, vec_ok, chunk0 + (uint64_t)lane * 4, w);
+            const bool whole0 = vec_ok && chunk0 + 4 * WAVE <= n_cigar;
+            if (whole0) { const uint4 v = *reinterpret_cast<const uint4 *>(cigar + chunk0 + (uint64_t)lane * 4); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            else depth_load4(cigar, n_cigar, vec_ok, chunk0 + (uint64_t)lane * 4, w);
             for (uint32_t o0 = 0; o0 < nrem; o0 += 4 * WAVE) {                      // o0: word offset of this chunk from chunk0
-                if (p1 + ref_carry >= T1) break;                                    // rest of the read lies right of the tile
+                if (base_rel >= TW) break;                                          // rest of the read lies right of the tile
                 const bool more = o0 + 4 * WAVE < nrem;
-                if (more) depth_load4(cigar, n_cigar, vec_ok, chunk0 + o0 + 4 * WAVE + (uint64_t)lane * 4, w1);   // next 1 KiB in flight
-                const int32_t o = (int32_t)o0 + lane * 4;
-                uint32_t len[4], rl[4], aln = 0, lane_ref = 0;
+                if (more) {                                                         // next 1 KiB in flight
+                    const uint64_t nx = chunk0 + o0 + 4 * WAVE;
+                    if (vec_ok && nx + 4 * WAVE <= n_cigar) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(cigar + nx + (uint64_t)lane * 4); w1[0] = v.x; w1[1] = v.y; w1[2] = v.z; w1[3] = v.w;
+                    } else depth_load4(cigar, n_cigar, vec_ok, nx + (uint64_t)lane * 4, w1);
+                }
+                // only the first and the last chunk of an item can hold words of a neighbouring read
+                if (!((int32_t)o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
+                    const int32_t o = (int32_t)o0 + lane * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (!((o + k >= c0rel) && ((uint32_t)(o + k) < nrem))) w[k] = (uint32_t)OP_P;
+                }
+                uint32_t rl[4], al[4], lane_ref = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const bool valid = (o + k >= c0rel) && ((uint32_t)(o + k) < nrem);
-                    const uint32_t op = valid ? (w[k] & 15u) : (uint32_t)OP_P;
-                    len[k] = valid ? (w[k] >> 4) : 0u;
-                    rl[k] = ((REF_OPS >> op) & 1u) ? len[k] : 0u;
-                    aln |= ((ALN_OPS >> op) & 1u) << k;
+                    const uint32_t op = w[k] & 15u, len = w[k] >> 4;
+                    rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)REF_OPS, op, 1u);    // all-ones when the op consumes the reference
+                    al[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)ALN_OPS, op, 1u);    // ... when its bases count toward depth
                     lane_ref += rl[k];
                 }
                 const uint32_t incl = wave_incl_sum_dpp(lane_ref);
-                uint64_t a1 = p1 + ref_carry + (incl - lane_ref);
+                int32_t rel = base_rel + (int32_t)(incl - lane_ref);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (((aln >> k) & 1u) && len[k]) {
-                        const uint64_t a = max(a1, T0), b = min(a1 + len[k], T1);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
-                        if (a < b) {
-                            atomicAdd(&diff[a - T0], 1u);
-                            atomicAdd(&diff[b - T0], 0xffffffffu);
-                        }
+                    const int32_t a = max(rel, 0), b = min(rel + (int32_t)al[k], TW);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
+                    if (a < b) {
+                        atomicAdd(&diff[a], 1u);
+                        atomicAdd(&diff[b], 0xffffffffu);
                     }
-                    a1 += rl[k];
+                    rel += (int32_t)rl[k];
                 }
-                ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                base_rel += (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 if (more) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) w[k] = w1[k];
