@@ -28,10 +28,16 @@ struct Chunk {
     uint32_t w[4];
 };
 
-__device__ __forceinline__ Chunk load_chunk(const uint32_t *__restrict__ cigar, uint64_t idx, uint64_t n_cigar, int vec_ok)
+// `base` = first word of the 1 KiB chunk (wave-uniform), lane l takes words base + 4l .. base + 4l + 3. Only the last chunk of
+// the whole array can be partial, so the bounds test is done once per wave, not per lane.
+__device__ __forceinline__ Chunk load_chunk(const uint32_t *__restrict__ cigar, uint64_t base, int lane, uint64_t n_cigar, int vec_ok)
 {
     Chunk c;
-    if (vec_ok && idx + 4 <= n_cigar) {
+    const uint64_t idx = base + (uint64_t)lane * 4;
+    if (vec_ok && base + 4 * WAVE <= n_cigar) {
+        uint4 v = *reinterpret_cast<const uint4 *>(cigar + idx);
+        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+    } else if (vec_ok && idx + 4 <= n_cigar) {
         uint4 v = *reinterpret_cast<const uint4 *>(cigar + idx);
         c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
     } else {
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
     }
     const uint64_t batch_end_word = cigar_off[rb + nb_reads];        // wave-uniform
     if (__ballot(l_uns != 0) && lane == 0) cnt->unsorted = 1u;
-    Chunk first = load_chunk(cigar, (bcast64(l_c0, 0) & ~255ull) + (uint64_t)lane * 4, n_cigar, vec_ok);
+    Chunk first = load_chunk(cigar, bcast64(l_c0, 0) & ~255ull, lane, n_cigar, vec_ok);
     for (uint32_t ri = 0; ri < (uint32_t)nb_reads; ri++) {
         const uint64_t r = rb + ri;
         const bool have_next = ri + 1 < (uint32_t)nb_reads;
@@ -173,25 +179,34 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
             if (lane == 0 && chunk > c0) ckpt[chunk >> 8] = ref_carry;     // reference offset of this read at word `chunk` (depth.hip)
             Chunk nxt;
             const bool more = chunk + 4 * WAVE < c1;
-            if (more) nxt = load_chunk(cigar, chunk + 4 * WAVE + (uint64_t)lane * 4, n_cigar, vec_ok);   // prefetch next 1 KiB
+            if (more) nxt = load_chunk(cigar, chunk + 4 * WAVE, lane, n_cigar, vec_ok);   // prefetch next 1 KiB
             else if (have_next) {                                                                        // last chunk: next read's first
-                first = load_chunk(cigar, next_base + (uint64_t)lane * 4, n_cigar, vec_ok);
+                first = load_chunk(cigar, next_base, lane, n_cigar, vec_ok);
                 next_first_issued = true;
             }
 
+            // only the first and the last chunk of a read can hold words of its neighbours: mask those to a no-op (P, length 0)
+            if (!(chunk >= c0 && chunk + 4 * WAVE <= c1)) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (!((uint32_t)(rel + k) < n_words)) cur.w[k] = (uint32_t)OP_P;   // also catches rel + k < 0
+            }
             uint32_t len[4], op[4], rl[4], ql[4];
-            uint32_t lane_ref = 0, lane_q = 0, big = 0, qst = 0;
+            uint32_t lane_ref = 0, lane_q = 0, max_cand = 0, qst = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const bool valid = (uint32_t)(rel + k) < n_words;          // also false for rel + k < 0
-                len[k] = valid ? (cur.w[k] >> 4) : 0u;
-                op[k] = valid ? (cur.w[k] & 15u) : (uint32_t)OP_P;
-                rl[k] = ((REF_OPS >> op[k]) & 1u) ? len[k] : 0u;
-                ql[k] = ((QRY_OPS >> op[k]) & 1u) ? len[k] : 0u;
+                op[k] = cur.w[k] & 15u;
+                len[k] = cur.w[k] >> 4;
+                rl[k] = len[k] & (uint32_t)__builtin_amdgcn_sbfe((int)REF_OPS, op[k], 1u);     // all-ones mask when the op consumes the reference
+                ql[k] = len[k] & (uint32_t)__builtin_amdgcn_sbfe((int)QRY_OPS, op[k], 1u);
                 lane_ref += rl[k];
                 lane_q += ql[k];
-                big |= (((CAND_OPS >> op[k]) & 1u) && len[k] >= min_oplen) ? 1u : 0u;   // only I / D / S ops can become signatures
-                qst |= (QST_OPS >> op[k]) & 1u;
+                max_cand = max(max_cand, len[k] & (uint32_t)__builtin_amdgcn_sbfe((int)CAND_OPS, op[k], 1u));   // only I / D / S ops can become signatures
+            }
+            // a conservative trigger for the slow path, which re-tests every op exactly
+            const uint32_t big = max_cand >= min_oplen ? 1u : 0u;
+            if (qs < 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) qst |= (QST_OPS >> op[k]) & 1u;
             }
             const uint32_t incl_ref = wave_incl_sum_dpp(lane_ref);
             const bool need_q = (qs < 0) || (emit_ok && __ballot(big != 0) != 0);
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
             ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)incl_ref, 63);
             if (more) cur = nxt;
         }
-        if (have_next && !next_first_issued) first = load_chunk(cigar, next_base + (uint64_t)lane * 4, n_cigar, vec_ok);
+        if (have_next && !next_first_issued) first = load_chunk(cigar, next_base, lane, n_cigar, vec_ok);
 
         const uint32_t q_total = wave_total_dpp(acc_q);
         if (lane == 0) {
