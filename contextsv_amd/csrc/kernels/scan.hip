@@ -93,7 +93,9 @@ __device__ __forceinline__ ScanMd scan_load_md(uint64_t r, uint64_t n_reads, con
     return m;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
+// 6 waves/SIMD (80 VGPRs, a dozen spilled dwords on the signature path) instead of 5 at the natural 95: the walk is bound by
+// occupancy
+__global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint8_t *__restrict__ mapq, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
     int vec_ok, uint32_t depth_len, uint32_t start_limit, uint32_t min_oplen, uint32_t min_mapq, int emit,
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cigar_scan_kernel(
         // sv_caller.cpp:526
         const bool emit_ok = emit && !(fl & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && mq >= min_mapq;
 
-        // The kernel is VALU-issue-bound, so the common chunk does the minimum: decode, ONE DPP scan (reference
+        // The common chunk does the minimum: decode, ONE DPP scan (reference
         // cursor: needed for the checkpoint and ref_end), lane-local query sums. Query cursors, skipped-clip
         // bookkeeping and signature assembly run only in chunks that contain an op >= min_oplen or that still
         // have to find query_start.
