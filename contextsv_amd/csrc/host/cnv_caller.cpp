@@ -1,5 +1,8 @@
 #include "cnv_caller.h"
 
+#include <fstream>
+#include <stdexcept>
+
 #include <algorithm>
 #include <stdexcept>
 
@@ -160,7 +163,7 @@ void CNVCaller::runCIGARCopyNumberPrediction(const std::string &chr, std::vector
 
 void CNVCaller::runCopyNumberPredictions(const std::string &chr, const CHMM &hmm, const std::vector<std::pair<uint32_t, uint32_t>> &regions,
                                          double mean_chr_cov, csv_shard *shard, const SNPSource &snps,
-                                         std::vector<std::tuple<double, SVType, Genotype, int>> &results) const
+                                         std::vector<std::tuple<double, SVType, Genotype, int>> &results, uint32_t depth_len) const
 {
     results.assign(regions.size(), std::make_tuple(0.0, SVType::UNKNOWN, Genotype::UNKNOWN, 0));
     std::vector<size_t> idx;
@@ -173,12 +176,28 @@ void CNVCaller::runCopyNumberPredictions(const std::string &chr, const CHMM &hmm
         idx.push_back(k); valid.push_back(regions[k]);
     }
     if (idx.empty()) return;
+    // --save-cnv: the half-length windows before and after each region ride in the same device batch (:176-198)
+    const size_t nv = valid.size();
+    std::vector<std::pair<uint32_t, uint32_t>> batch = valid;
+    std::vector<long> before_at(nv, -1), after_at(nv, -1);
+    if (save_cnv_data) {
+        for (size_t q = 0; q < nv; q++) {
+            const int start_pos = (int)valid[q].first, end_pos = (int)valid[q].second;
+            const int half = (end_pos - start_pos) / 2;
+            const int b0 = std::max(1, start_pos - half), b1 = std::max(1, start_pos - 1);
+            if (b0 < b1) { before_at[q] = (long)batch.size(); batch.emplace_back((uint32_t)b0, (uint32_t)b1); }
+            const int last = (int)depth_len - 1;
+            const int a0 = std::min(last, end_pos + 1), a1 = std::min(last, end_pos + half);
+            if (a0 < a1) { after_at[q] = (long)batch.size(); batch.emplace_back((uint32_t)a0, (uint32_t)a1); }
+        }
+    }
     std::vector<SNPData> data;
-    querySNPRegions(valid, shard, mean_chr_cov, snps, data);
+    querySNPRegions(batch, shard, mean_chr_cov, snps, data);
+    std::vector<SNPData> sv_data(data.begin(), data.begin() + (std::ptrdiff_t)nv);
     std::vector<std::pair<std::vector<int>, double>> pred;
-    runViterbi(hmm, data, pred);
+    runViterbi(hmm, sv_data, pred);
     for (size_t q = 0; q < idx.size(); q++) {
-        const std::vector<int> &seq = pred[q].first;
+        std::vector<int> &seq = pred[q].first;
         if (seq.empty()) continue;                                       // :206-209
         double pct[7] = {0, 0, 0, 0, 0, 0, 0};
         const double state_count = (double)seq.size();
@@ -190,17 +209,86 @@ void CNVCaller::runCopyNumberPredictions(const std::string &chr, const CHMM &hmm
         int max_state = 0;
         if (largest_non_neutral_pct > 0.3) max_state = non_neutral_state;   // :227-238
         else if (pct[3] > 0.3) max_state = 3;
-        results[idx[q]] = std::make_tuple(pred[q].second, getSVTypeFromCNState(max_state), getGenotypeFromCNState(max_state), max_state);
+        const SVType predicted = getSVTypeFromCNState(max_state);
+        results[idx[q]] = std::make_tuple(pred[q].second, predicted, getGenotypeFromCNState(max_state), max_state);
+
+        const uint32_t start_pos = valid[q].first, end_pos = valid[q].second;
+        const bool change = predicted != SVType::UNKNOWN && predicted != SVType::NEUTRAL;
+        if (save_cnv_data && change && (end_pos - start_pos) >= 30000u) {          // :243-284
+            SNPData none_before, none_after;
+            SNPData &snp_data = data[q];
+            SNPData &before_sv = before_at[q] >= 0 ? data[(size_t)before_at[q]] : none_before;
+            SNPData &after_sv = after_at[q] >= 0 ? data[(size_t)after_at[q]] : none_after;
+            snp_data.state_sequence = std::move(seq);
+            for (SNPData *d : {&snp_data, &before_sv, &after_sv})
+                for (size_t i = 0; i < d->pos.size(); i++)
+                    if (!d->is_snp[i]) { d->baf[i] = 0.0; d->pfb[i] = 0.0; }
+            printMessage("Saving SV copy number predictions to " + cnv_output_file + "...");
+            saveSVCopyNumberToJSON(before_sv, after_sv, snp_data, chr, start_pos, end_pos, getSVTypeString(predicted), pred[q].second, cnv_output_file);
+        }
     }
 }
 
+namespace {
+template <class V>
+void json_array(std::ostream &out, const char *indent_key, const V &v, const char *tail)
+{
+    out << indent_key << "[";
+    for (size_t i = 0; i < v.size(); ++i) {
+        out << v[i];
+        if (i + 1 < v.size()) out << ", ";
+    }
+    out << tail;
+}
+void json_block(std::ostream &out, const char *name, const SNPData &d, bool with_states, const char *close)
+{
+    out << "  \"" << name << "\": {\n";
+    json_array(out, "    \"positions\": ", d.pos, "],\n");
+    json_array(out, "    \"b_allele_freq\": ", d.baf, "],\n");
+    json_array(out, "    \"population_freq\": ", d.pfb, "],\n");
+    json_array(out, "    \"log2_ratio\": ", d.log2_cov, "],\n");
+    if (with_states) json_array(out, "    \"states\": ", d.state_sequence, "],\n");
+    json_array(out, "    \"is_snp\": ", d.is_snp, "]\n");
+    out << close;
+}
+}  // namespace
+
+void CNVCaller::saveSVCopyNumberToJSON(SNPData &before_sv, SNPData &after_sv, SNPData &snp_data, const std::string &chr, uint32_t start, uint32_t end,
+                                       const std::string &sv_type, double likelihood, const std::string &filepath) const
+{
+    std::ofstream json_file(filepath, std::ios::app);
+    if (!json_file.is_open()) throw std::runtime_error("ERROR: Could not open JSON file for writing: " + filepath);   // the reference exits (:815-819)
+    json_file.seekp(0, std::ios::end);
+    if (json_file.tellp() == std::streampos(0)) json_file << "[\n";      // first record opens the array (:823-829)
+    else json_file << "},\n";                                            // later ones close their predecessor
+    json_file << "{\n";
+    json_file << "  \"chromosome\": \"" << chr << "\",\n";
+    json_file << "  \"start\": " << start << ",\n";
+    json_file << "  \"end\": " << end << ",\n";
+    json_file << "  \"sv_type\": \"" << sv_type << "\",\n";
+    json_file << "  \"likelihood\": " << likelihood << ",\n";
+    json_file << "  \"size\": " << (end - start + 1) << ",\n";
+    json_block(json_file, "before_sv", before_sv, false, "  },\n");
+    json_block(json_file, "after_sv", after_sv, false, "  },\n");
+    json_block(json_file, "sv", snp_data, true, "  }\n");
+    json_file.close();
+    printMessage("Saved copy number predictions for " + chr + ":" + std::to_string(start) + "-" + std::to_string(end) + " to " + filepath);
+}
+
+void CNVCaller::closeJSON(const std::string &filepath)
+{
+    std::ofstream json_file(filepath, std::ios::app);
+    json_file << "}\n";
+    json_file << "]";
+}
+
 void CNVCaller::runSplitReadCopyNumberPredictions(const std::string &chr, std::vector<SVCall> &split_sv_calls, const CHMM &hmm, double mean_chr_cov,
-                                                  csv_shard *shard, const SNPSource &snps) const
+                                                  csv_shard *shard, const SNPSource &snps, uint32_t depth_len) const
 {
     std::vector<std::pair<uint32_t, uint32_t>> regions;
     for (const SVCall &c : split_sv_calls) regions.emplace_back(c.start, c.end);
     std::vector<std::tuple<double, SVType, Genotype, int>> results;
-    runCopyNumberPredictions(chr, hmm, regions, mean_chr_cov, shard, snps, results);
+    runCopyNumberPredictions(chr, hmm, regions, mean_chr_cov, shard, snps, results, depth_len);
 
     auto take_prediction = [](SVCall &c, double lh, Genotype g, int cn) {
         c.aln_type.set((size_t)SVDataType::HMM); c.hmm_likelihood = lh; c.genotype = g; c.cn_state = cn;

@@ -51,6 +51,8 @@ public:
     explicit CNVCaller(csv_ctx *ctx) : ctx(ctx) {}
     int sample_size = 20;            // --sample-size (input_data.cpp:18-37)
     uint32_t min_cnv_length = 2000;  // --min-cnv
+    bool save_cnv_data = false;      // --save-cnv: CNVCalls.json records for the plotting scripts (cnv_caller.cpp:179-198, :243-284)
+    std::string cnv_output_file;     //   <outdir>/CNVCalls.json (main.cpp:109-118)
 
     static Genotype getGenotypeFromCNState(int cn_state);   // cnv_caller.h:76-97 of the reference
 
@@ -65,14 +67,21 @@ public:
     void runCIGARCopyNumberPrediction(const std::string &chr, std::vector<SVCall> &sv_candidates, const CHMM &hmm, double mean_chr_cov,
                                       csv_shard *shard, const SNPSource &snps) const;
 
-    // cnv_caller.cpp:166-287 for a batch of regions (the JSON side output of --save-cnv is not produced)
+    // cnv_caller.cpp:166-287 for a batch of regions. With save_cnv_data the flanking half-length windows are queried too and
+    // every region with a copy-number change of >= 30 kb appends a record to cnv_output_file; depth_len (the depth map's size)
+    // bounds the right flank as pos_depth_map.size() does there.
     void runCopyNumberPredictions(const std::string &chr, const CHMM &hmm, const std::vector<std::pair<uint32_t, uint32_t>> &regions,
                                   double mean_chr_cov, csv_shard *shard, const SNPSource &snps,
-                                  std::vector<std::tuple<double, SVType, Genotype, int>> &results) const;
+                                  std::vector<std::tuple<double, SVType, Genotype, int>> &results, uint32_t depth_len = 0) const;
+
+    // cnv_caller.cpp:811-974 (appends one record, opening the array when the file is empty) and utils.cpp:63-71 (closes it)
+    void saveSVCopyNumberToJSON(SNPData &before_sv, SNPData &after_sv, SNPData &snp_data, const std::string &chr, uint32_t start, uint32_t end,
+                                const std::string &sv_type, double likelihood, const std::string &filepath) const;
+    static void closeJSON(const std::string &filepath);
 
     // sv_caller.cpp:983-1064 — the five-way update / duplicate rule for split-read candidates
     void runSplitReadCopyNumberPredictions(const std::string &chr, std::vector<SVCall> &split_sv_calls, const CHMM &hmm,
-                                           double mean_chr_cov, csv_shard *shard, const SNPSource &snps) const;
+                                           double mean_chr_cov, csv_shard *shard, const SNPSource &snps, uint32_t depth_len = 0) const;
 
 private:
     csv_ctx *ctx;

@@ -353,7 +353,7 @@ int csvhost_run(csv_ctx *ctx, int n_contigs, const uint64_t *read_off, const uin
                 const csv_hmm *hmm, double eps, double min_pts_pct, int sample_size, uint32_t min_cnv,
                 csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out,
                 const csvhost_fasta *fasta, const char *vcf_dir, const char *gap_path, const char *file_date,
-                char *alt_buf, uint64_t alt_cap, uint64_t *alt_off)
+                char *alt_buf, uint64_t alt_cap, uint64_t *alt_off, int save_cnv)
 {
     GUARD({
         std::vector<ChromosomeInput> contigs((size_t)n_contigs);
@@ -379,6 +379,7 @@ int csvhost_run(csv_ctx *ctx, int n_contigs, const uint64_t *read_off, const uin
             P.ref_genome = fasta_genome(fasta);
             P.vcf.output_dir = vcf_dir; P.vcf.assembly_gaps = gap_path ? gap_path : ""; P.vcf.file_date = file_date ? file_date : "";
         }
+        P.save_cnv = save_cnv != 0;
         SVCaller caller(ctx);
         std::unordered_map<std::string, std::vector<SVCall>> calls;
         caller.run(contigs, chmm_from_pod(hmm), P, calls);
@@ -606,7 +607,7 @@ struct csvhost_bam_stats { uint64_t n_contigs, n_reads, n_cigar, bam_bytes; doub
 // SVCaller::runBam: chrs = '\n'-separated contig names or null (all). SNPs: none (every window gets the dummy observation).
 // Calls come back grouped by contig in header order, with their contig index in out_tid.
 int csvhost_run_bam(csv_ctx *ctx, const char *bam_path, const char *chrs, int threads, const csv_hmm *hmm, double eps, double min_pts_pct,
-                    int sample_size, uint32_t min_cnv, int passes /* bit 0: split-read pass, bit 1: CIGAR copy-number pass */, const csvhost_fasta *fasta, const char *vcf_dir, const char *gap_path,
+                    int sample_size, uint32_t min_cnv, int passes /* bit 0: split-read pass, bit 1: CIGAR copy-number pass, bit 2: --save-cnv */, const csvhost_fasta *fasta, const char *vcf_dir, const char *gap_path,
                     const char *file_date, csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out, csvhost_bam_stats *stats,
                     const char *snp_vcf, const char *pfb_table, const char *ethnicity)
 {
@@ -618,7 +619,7 @@ int csvhost_run_bam(csv_ctx *ctx, const char *bam_path, const char *chrs, int th
             p = e ? e + 1 : p + strlen(p);
         }
         RunParams P; P.dbscan_epsilon = eps; P.dbscan_min_pts_pct = min_pts_pct; P.sample_size = sample_size; P.min_cnv_length = min_cnv;
-        P.split_svs = (passes & 1) != 0; P.cigar_cn = (passes & 2) != 0;
+        P.split_svs = (passes & 1) != 0; P.cigar_cn = (passes & 2) != 0; P.save_cnv = (passes & 4) != 0;
         P.snp_vcf = snp_vcf ? snp_vcf : ""; P.pfb_table = pfb_table ? pfb_table : ""; P.ethnicity = ethnicity ? ethnicity : "";
         if (fasta && vcf_dir) {
             P.ref_genome = fasta_genome(fasta);

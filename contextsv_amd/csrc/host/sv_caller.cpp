@@ -1,6 +1,7 @@
 #include "sv_caller.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <chrono>
 #include <condition_variable>
 #include <exception>
@@ -263,6 +264,7 @@ void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
     std::vector<std::string> names;
     std::vector<csv_shard *> shards;
     std::vector<ChrStats> stats;
+    std::vector<uint32_t> depth_lens;
     std::vector<const SNPSource *> snps;
     std::vector<SplitRecord> records;
     std::vector<std::string> qnames;
@@ -277,6 +279,7 @@ void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
             shards.push_back(nullptr);
             stats.emplace_back();
             snps.push_back(c.snps);
+            depth_lens.push_back(c.depth_len);
             index_of[c.name] = i;
             std::vector<SVCall> calls;
             if (P.cigar_svs) processChromosome(c.name, c.reads, c.seq, c.depth_len, P.dbscan_epsilon, P.dbscan_min_pts_pct, calls, stats[i], &shards[i]);
@@ -294,6 +297,12 @@ void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
         }
         CNVCaller cnv(ctx);
         cnv.sample_size = P.sample_size; cnv.min_cnv_length = P.min_cnv_length;
+        if (P.save_cnv && !P.vcf.output_dir.empty()) {                                 // main.cpp:109-118
+            cnv.save_cnv_data = true;
+            cnv.cnv_output_file = P.vcf.output_dir + "/CNVCalls.json";
+            std::remove(cnv.cnv_output_file.c_str());
+            printMessage("Saving CNV data to: " + cnv.cnv_output_file);
+        }
         if (P.cigar_svs && P.cigar_cn) {                                               // :865-881
             printMessage("Running copy number predictions on CIGAR SVs...");
             for (auto &entry : whole_genome_sv_calls) {
@@ -311,7 +320,7 @@ void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
                 if (entry.second.empty()) continue;
                 const size_t i = index_of.at(entry.first);
                 cnv.runSplitReadCopyNumberPredictions(entry.first, entry.second, hmm, stats[i].mean_chr_cov, shards[i],
-                                                      snps[i] ? *snps[i] : (const SNPSource &)no_snps);
+                                                      snps[i] ? *snps[i] : (const SNPSource &)no_snps, depth_lens[i]);
             }
             if (P.merge_split_svs) for (auto &entry : split_calls) mergeSVs(entry.second, 0.1, 2, true);
             for (auto &entry : split_calls) {
@@ -320,6 +329,7 @@ void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
             }
         }
         if (P.merge_final_svs) for (auto &entry : whole_genome_sv_calls) mergeSVs(entry.second, 0.1, 2, true);   // :919-927
+        if (cnv.save_cnv_data) CNVCaller::closeJSON(cnv.cnv_output_file);                                       // :929-931
         uint32_t total = 0;
         for (const auto &entry : whole_genome_sv_calls) {
             total += getSVCount(entry.second);

@@ -56,6 +56,7 @@ struct RunParams {
     int sample_size = 20;                   // --sample-size
     uint32_t min_cnv_length = 2000;         // --min-cnv
     bool cigar_svs = true, cigar_cn = true, split_svs = true, merge_split_svs = true, merge_final_svs = true;   // sv_caller.cpp:749-753
+    bool save_cnv = false;                  // --save-cnv: <vcf.output_dir>/CNVCalls.json (main.cpp:109-118, sv_caller.cpp:929-931)
     std::string snp_vcf;                    // --snp: the sample's SNP VCF (runBam; "" = no SNPs, every window gets the dummy observation)
     std::string pfb_table;                  // --pfb: "<chr>=<gnomAD VCF>" table
     std::string ethnicity;                  // --eth: AF_<eth> instead of AF

@@ -59,7 +59,7 @@ def load() -> C.CDLL:
                                           C.c_double, C.c_int, C.c_uint32, _P, _P, _P, _P, C.c_uint64]
     lib.csvhost_split_signatures.argtypes = [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_run.argtypes = [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_lib.csv_hmm), C.c_double, C.c_double,
-                                C.c_int, C.c_uint32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), _P, C.c_char_p, C.c_char_p, C.c_char_p, _P, C.c_uint64, _P]
+                                C.c_int, C.c_uint32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), _P, C.c_char_p, C.c_char_p, C.c_char_p, _P, C.c_uint64, _P, C.c_int]
     lib.csvhost_read_chmm.argtypes = [C.c_char_p, C.POINTER(_lib.csv_hmm), C.POINTER(C.c_int32)]
     lib.csvhost_sort_select_check.argtypes = [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.csvhost_fasta_open.restype = _P
@@ -300,7 +300,7 @@ def split_signatures(ctx: Context, tid, pos, flag, mapq, ref_end, q_start, q_end
 
 
 def run(ctx: Context, contigs: list, hmm, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, genome=None, vcf_dir=None,
-        gap_path=None, file_date=None, want_alts=False):
+        gap_path=None, file_date=None, want_alts=False, save_cnv=False):
     """SVCaller::run mirror. contigs: list of dicts {reads: Reads, depth_len, qname_id: uint32[n], snps: dict}; contig t is named
     "contig<t>". With genome (ReferenceGenome) and vcf_dir the run ends by writing <vcf_dir>/output.vcf.
     -> (merged calls, contig id per call[, ALT strings])."""
@@ -333,7 +333,7 @@ def run(ctx: Context, contigs: list, hmm, eps=0.1, min_pts_pct=0.1, sample_size=
                               tid.ctypes.data, cap, C.byref(n),
                               genome.h if genome is not None and vcf_dir else None, os.fsencode(vcf_dir) if vcf_dir else None,
                               os.fsencode(gap_path) if gap_path else None, file_date.encode() if file_date else None,
-                              alt_buf.ctypes.data if want_alts else None, alt_cap, alt_off.ctypes.data if want_alts else None))
+                              alt_buf.ctypes.data if want_alts else None, alt_cap, alt_off.ctypes.data if want_alts else None, int(save_cnv)))
     if want_alts:
         raw = alt_buf.tobytes()
         alts = [raw[int(alt_off[i]):int(alt_off[i + 1])] for i in range(n.value)]
@@ -517,7 +517,7 @@ def write_bam(path: str, ref_names, ref_lens, tid, reads: Reads, qnames, seq_off
                                     p(mapq), p(coff), p(cig), "\n".join(qnames).encode(), p(so), p(sq), p(ls), level, threads))
 
 
-def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True, cigar_cn=True,
+def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True, cigar_cn=True, save_cnv=False,
             genome: ReferenceGenome | None = None, vcf_dir=None, gap_path=None, file_date=None, capacity: int = 1 << 20,
             snp_vcf=None, pfb_table=None, ethnicity=""):
     """SVCaller::runBam: the whole run fed from a coordinate-sorted, indexed BAM. -> (calls, contig index per call, stats dict)."""
@@ -526,7 +526,7 @@ def run_bam(ctx: Context, bam_path: str, hmm, chromosomes=None, threads=8, eps=0
     n = C.c_uint64(0)
     st = bam_stats()
     _check(load().csvhost_run_bam(ctx.h, os.fsencode(bam_path), "\n".join(chromosomes).encode() if chromosomes else None, threads, C.byref(hmm), eps,
-                                  min_pts_pct, sample_size, min_cnv, int(split_svs) | (int(cigar_cn) << 1), genome.h if genome is not None and vcf_dir else None,
+                                  min_pts_pct, sample_size, min_cnv, int(split_svs) | (int(cigar_cn) << 1) | (int(save_cnv) << 2), genome.h if genome is not None and vcf_dir else None,
                                   os.fsencode(vcf_dir) if vcf_dir else None, os.fsencode(gap_path) if gap_path else None,
                                   file_date.encode() if file_date else None, out.ctypes.data, tid.ctypes.data, capacity, C.byref(n), C.byref(st),
                                   os.fsencode(snp_vcf) if snp_vcf else None, os.fsencode(pfb_table) if pfb_table else None, ethnicity.encode()))

@@ -122,7 +122,7 @@ def test_whole_path_end_to_end(ctx, oracle, tmp_path):
         f.write("contig0\t100000\t400000\ncontig2\t0\t50000\n")
     genome = host.ReferenceGenome(fasta)
     got, got_tid, got_alts = host.run(ctx, contigs, hmm, eps=0.1, min_pts_pct=0.1, genome=genome, vcf_dir=str(tmp_path), gap_path=gaps,
-                                      file_date="20250926", want_alts=True)
+                                      file_date="20250926", want_alts=True, save_cnv=True)
 
     # ---- the same chain from the oracle's pieces --------------------------------------------------
     cigar_calls, depths, means = [], [], []
@@ -175,3 +175,36 @@ def test_whole_path_end_to_end(ctx, oracle, tmp_path):
         assert [l for l in got_lines if l.startswith(pre)] == [l for l in exp_lines if l.startswith(pre)]
     assert len(got_lines) == len(exp_lines)
     assert any("\tAssemblyGap\t" in l for l in got_lines) and any("SVTYPE=DEL" in l for l in got_lines) and any("SVTYPE=INS" in l for l in got_lines)
+
+    # ---- --save-cnv: CNVCalls.json (cnv_caller.cpp:243-284, :811-974): one record per split-read region of >= 30 kb with a predicted
+    # copy-number change, arrays = the observation vectors of the region and of its two flanking half-length windows
+    import json
+    text = (tmp_path / "CNVCalls.json").read_text()
+    assert text.endswith("}\n]")
+    if text == "}\n]":
+        pytest.skip("no >= 30 kb copy-number change among the split-read regions of this data set")
+    records = json.loads(text)
+    assert len(records) >= 1
+    for rec in records:
+        t = int(rec["chromosome"][len("contig"):])
+        start, end = rec["start"], rec["end"]
+        assert rec["size"] == end - start + 1 and end - start >= 30000 and rec["sv_type"] in ("DEL", "DUP", "LOH")
+        half = (end - start) // 2
+        last = len(depths[t]) - 1
+        windows = {"sv": (start, end), "before_sv": (max(1, start - half), max(1, start - 1)), "after_sv": (min(last, end + 1), min(last, end + half))}
+        for name, (a, b) in windows.items():
+            got_w = rec[name]
+            if name != "sv" and not a < b:
+                assert got_w["positions"] == []
+                continue
+            exp_w = oracle.query_snp_region(depths[t], a, b, means[t], 20, contigs[t]["snps"])
+            assert got_w["positions"] == exp_w["pos"].tolist()
+            assert got_w["is_snp"] == exp_w["is_snp"].astype(int).tolist()
+            keep = exp_w["is_snp"]
+            np.testing.assert_allclose(got_w["b_allele_freq"], np.where(keep, exp_w["baf"], 0.0), rtol=2e-5, atol=1e-12)
+            np.testing.assert_allclose(got_w["population_freq"], np.where(keep, exp_w["pfb"], 0.0), rtol=2e-5, atol=1e-12)
+            np.testing.assert_allclose(got_w["log2_ratio"], exp_w["log2_cov"], rtol=2e-5, atol=1e-12)
+        sv = oracle.query_snp_region(depths[t], start, end, means[t], 20, contigs[t]["snps"])
+        st, ll = oracle.viterbi(hmm, sv["log2_cov"], sv["baf"], sv["pfb"], np.array([0, len(sv["pos"])], np.uint64))
+        assert rec["sv"]["states"] == st.tolist()
+        assert abs(rec["likelihood"] - ll[0]) <= 2e-5 * abs(ll[0]) + 1e-9
