@@ -136,7 +136,9 @@ void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, 
                         const int32_t *ref_end, const int32_t *pmax_end, const uint32_t *ckpt, uint32_t depth_len,
                         uint32_t *depth, ScanCounters *cnt, void *tmp /* depth_tiles_tmp_bytes(depth_len) */);
 size_t depth_tiles_tmp_bytes(uint32_t depth_len);
-static inline size_t ckpt_bytes(uint64_t n_cigar) { return ((n_cigar >> 8) + 2) * sizeof(uint32_t); }
+// reference-offset checkpoints every CKPT_WORDS CIGAR words (scan.hip writes them, depth.hip starts its walks from them)
+constexpr int CKPT_SHIFT = 6, CKPT_WORDS = 1 << CKPT_SHIFT;
+static inline size_t ckpt_bytes(uint64_t n_cigar) { return ((n_cigar >> CKPT_SHIFT) + 2) * sizeof(uint32_t); }
 void launch_min_pts(hipStream_t s, ScanCounters *cnt, double min_pts_pct);
 void launch_depth_lookup(hipStream_t s, const uint32_t *depth, uint32_t depth_len, const uint32_t *pos, uint64_t n, int32_t *out);
 // sort.hip

@@ -12,7 +12,7 @@
 //      prefix maximum of the read ends bounds the range on the left);
 //   2. all threads together build an LDS work list: thread t loads candidate t's metadata, drops reads
 //      that end left of the tile or fail the depth filter, and binary-searches the read's checkpoints
-//      (scan.hip records the reference offset of a read at every 256-word CIGAR boundary) for the last
+//      (scan.hip records the reference offset of a read at every 64-word CIGAR boundary) for the last
 //      boundary left of the tile;
 //   3. waves pull items from an LDS counter and walk 1 KiB CIGAR chunks from that boundary (16-byte loads,
 //      one DPP wave scan per chunk, next chunk in flight), applying +1/-1 with LDS atomics, until the
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int vec_ok, int dvec_ok,
     const uint32_t *__restrict__ ord,        // nullptr: reads already sorted by pos; else the tile ranges index `ord`
     const int32_t *__restrict__ ref_end, const uint64_t *__restrict__ tile_range,
-    const uint32_t *__restrict__ ckpt,       // reference offset of the owning read at every 256-word boundary (scan.hip)
+    const uint32_t *__restrict__ ckpt,       // reference offset of the owning read at every CKPT_WORDS-word boundary (scan.hip)
     uint32_t depth_len, uint32_t *__restrict__ depth, ScanCounters *__restrict__ cnt)
 {
     __shared__ uint32_t diff[DEPTH_TILE + 4];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
 
     // Work list: the candidates are examined ONCE per tile by all threads together — thread t takes candidate t of the
     // batch, loads its metadata (coalesced across threads), drops reads that end left of the tile or fail the depth filter
-    // (cnv_caller.cpp:491-495), and binary-searches the read's checkpoints for the last 256-word boundary left of the tile.
+    // (cnv_caller.cpp:491-495), and searches the read's checkpoints for the last 64-word boundary left of the tile.
     // Surviving (start chunk, reference carry, word range) items go to LDS; the waves then pull items from an LDS counter
     // and go straight to CIGAR chunk loads, with no per-read metadata or checkpoint latency on their critical path.
     for (uint64_t cb = k_lo; cb < k_hi; cb += WL_CAP) {
@@ -222,11 +222,24 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
             const bool ok = ((int64_t)ref_end[r] >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && c1 > c0;
             if (ok) {
                 const uint64_t p1 = (uint64_t)(uint32_t)pos[r] + 1;                 // 1-based first reference position (:498)
-                const uint64_t g0 = c0 >> 8, g1 = (c1 - 1) >> 8;
+                const uint64_t g0 = c0 >> CKPT_SHIFT, g1 = (c1 - 1) >> CKPT_SHIFT;
                 uint64_t lo = g0 + 1, hi = g1 + 1;                                   // first boundary NOT left of the tile
+                // The reference offset grows almost linearly with the word index, so the boundary is guessed by interpolation and
+                // three independent probes around the guess usually close the bracket: one round trip where a bisection of the
+                // read's ~20 checkpoints is five dependent ones (this search sits on every tile's critical path).
+                if (lo < hi && p1 <= T0) {
+                    const uint64_t rlen = (uint64_t)((int64_t)ref_end[r] - (int64_t)p1 + 1);
+                    uint64_t guess = lo + (uint64_t)((double)(T0 - p1) / (double)(rlen ? rlen : 1) * (double)(hi - lo));
+                    guess = min(max(guess, lo), hi - 1);
+                    const uint64_t ga = guess > lo ? guess - 1 : lo, gb = guess, gc = min(guess + 1, hi - 1);
+                    const uint32_t ka = ckpt[ga], kb = ckpt[gb], kc = ckpt[gc];
+                    // f(g) = (p1 + ckpt[g] <= T0) is true up to the answer and false from it on
+                    if (p1 + kc <= T0) lo = gc + 1;
+                    else { hi = gc; if (p1 + kb <= T0) lo = gb + 1; else { hi = gb; if (p1 + ka <= T0) lo = ga + 1; else hi = ga; } }
+                }
                 while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (p1 + ckpt[mid] <= T0) lo = mid + 1; else hi = mid; }
-                uint64_t chunk = c0 & ~255ull; uint32_t carry = 0;
-                if (lo > g0 + 1) { chunk = (lo - 1) << 8; carry = ckpt[lo - 1]; }
+                uint64_t chunk = c0 & ~(uint64_t)(CKPT_WORDS - 1); uint32_t carry = 0;     // walks start on a checkpoint: at most 63 words re-read
+                if (lo > g0 + 1) { chunk = (lo - 1) << CKPT_SHIFT; carry = ckpt[lo - 1]; }
                 if (p1 + carry < T1) {                                               // else the whole read lies right of the tile
                     const uint32_t slot = atomicAdd(&wl_n, 1u);
                     wl_chunk[slot] = chunk;

@@ -178,7 +178,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
         int32_t rel = (int32_t)(base - c0) + lane * 4;   // index of this lane's first word relative to the read's first word
         Chunk cur = first;
         for (uint64_t chunk = base; chunk < c1; chunk += 4 * WAVE, rel += 4 * WAVE) {
-            if (lane == 0 && chunk > c0) ckpt[chunk >> 8] = ref_carry;     // reference offset of this read at word `chunk` (depth.hip)
             Chunk nxt;
             const bool more = chunk + 4 * WAVE < c1;
             if (more) nxt = load_chunk(cigar, chunk + 4 * WAVE, lane, n_cigar, vec_ok);   // prefetch next 1 KiB
@@ -211,6 +210,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
                 for (int k = 0; k < 4; k++) qst |= (QST_OPS >> op[k]) & 1u;
             }
             const uint32_t incl_ref = wave_incl_sum_dpp(lane_ref);
+            {   // checkpoints: the reference offset of this read at every CKPT_WORDS-th word strictly inside it (depth.hip starts its
+                // walks there); one store instruction per chunk, lanes 0, 16, 32, 48
+                const uint64_t w = chunk + (uint64_t)lane * 4;
+                if ((lane & (CKPT_WORDS / 4 - 1)) == 0 && w > c0 && w < c1) ckpt[w >> CKPT_SHIFT] = ref_carry + (incl_ref - lane_ref);
+            }
             const bool need_q = (qs < 0) || (emit_ok && __ballot(big != 0) != 0);
             if (need_q) {
                 // ---------------- slow path: query cursors --------------------------------------------------
