@@ -17,6 +17,7 @@
 #include "vcf_writer.h"
 #include "bam_io.h"
 #include "snp_io.h"
+#include "fast_inflate.h"
 #include <fstream>
 #include <algorithm>
 #include <vector>
@@ -696,6 +697,11 @@ int64_t csvhost_gnomad_contig(const char *chr, const char *pfb_path, char *buf, 
     if (buf && cap) memcpy(buf, g.data(), (size_t)std::min<uint64_t>(cap, g.size()));
     return (int64_t)g.size();
 }
+
+// ---- fast inflate / CRC (fast_inflate.h) on their own, for the tests -------------------------------------------
+// 1 = decoded (out filled), 0 = declined (the caller would use zlib); never touches memory outside the two buffers
+int csvhost_fast_inflate(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_len) { return fastz::inflate(in, in_len, out, out_len) ? 1 : 0; }
+uint32_t csvhost_fast_crc32(const uint8_t *buf, uint64_t len) { return fastz::crc32(buf, len); }
 
 // ---- HMM file + Viterbi seam ------------------------------------------------------------------
 int csvhost_read_chmm(const char *path, csv_hmm *out, int32_t *N)
