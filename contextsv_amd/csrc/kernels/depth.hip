@@ -221,7 +221,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
             const uint32_t fl = flag[r];
             const bool ok = ((int64_t)ref_end[r] >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && c1 > c0;
             if (ok) {
-                const uint64_t p1 = (uint64_t)(uint32_t)pos[r] + 1;                 // 1-based first reference position (:498)
+                const uint64_t p1 = (uint64_t)(uint32_t)((uint32_t)pos[r] + 1u);    // 1-based first reference position, in uint32 as there (:498): pos -1 wraps to 0
                 const uint64_t g0 = c0 >> CKPT_SHIFT, g1 = (c1 - 1) >> CKPT_SHIFT;
                 uint64_t lo = g0 + 1, hi = g1 + 1;                                   // first boundary NOT left of the tile
                 // The reference offset grows almost linearly with the word index, so the boundary is guessed by interpolation and

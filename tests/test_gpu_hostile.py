@@ -1,0 +1,66 @@
+"""Inputs no aligner writes but the seams must survive with the oracle's answers: zero-length ops, reads hanging over or lying
+beyond the contig end, positions that wrap in uint32, empty CIGARs, every record filtered, a one-position contig, unsorted shards."""
+import numpy as np
+import pytest
+
+from contextsv_amd import Reads
+
+pytestmark = pytest.mark.gpu
+M, I, D, N, S, H, P, EQ, X = range(9)
+
+
+def _hostile(seed, n_reads, depth_len, sorted_pos=True):
+    rng = np.random.default_rng(seed)
+    pos = rng.integers(-1, depth_len + 300, n_reads)
+    pos[rng.random(n_reads) < 0.02] = 2**31 - 20_000_000 - rng.integers(0, 50)  # far beyond any contig; every coordinate stays below 2^31 (the seams' documented domain)
+    if sorted_pos:
+        pos.sort()
+    flag = rng.choice([0, 0, 0, 16, 4, 256, 512, 1024, 2048, 2064], n_reads)
+    mapq = rng.choice([0, 19, 20, 60, 255], n_reads)
+    cig = []
+    for r in range(n_reads):
+        k = int(rng.choice([0, 1, 2, 5, 40, 300, 700]))
+        ops = []
+        for _ in range(k):
+            op = int(rng.choice([M, M, M, I, D, N, S, H, P, EQ, X]))
+            ln = int(rng.choice([0, 1, 3, 49, 50, 51, 200, 5000]))
+            ops.append((op, ln))
+        cig.append(ops)
+    return Reads.from_cigar_lists(pos, flag.astype(np.uint16), mapq.astype(np.uint8), cig)
+
+
+def _same_sigs(a, b):
+    assert len(a) == len(b)
+    for f in ("start", "end", "read", "qpos_kind"):
+        assert np.array_equal(a[f], b[f]), f
+
+
+@pytest.mark.parametrize("seed,n_reads,depth_len,sorted_pos", [(1, 400, 3000, True), (2, 400, 3000, False), (3, 64, 1, True),
+                                                              (4, 900, 70_000, True), (5, 30, 17, False)])
+def test_seams_on_hostile_shards(ctx, oracle, seed, n_reads, depth_len, sorted_pos):
+    reads = _hostile(seed, n_reads, depth_len, sorted_pos)
+    for min_oplen, min_mapq in ((50, 20), (1, 0)):
+        _same_sigs(ctx.cigar_scan(reads, depth_len, min_oplen, min_mapq), oracle.cigar_scan(reads, depth_len, min_oplen, min_mapq))
+    for g, o in zip(ctx.aln_intervals(reads), oracle.aln_intervals(reads)):
+        assert np.array_equal(g, o)
+    d, s, nz = ctx.depth(reads, depth_len)
+    od, os_, onz = oracle.depth(reads, depth_len)
+    assert np.array_equal(d, od) and (s, nz) == (os_, onz)
+    sh = ctx.upload(reads, depth_len)
+    try:
+        for pct in (0.1, 0.0):
+            res = sh.pipeline(eps=0.1, min_pts_pct=pct)
+            out = sh.fetch(res, want_depth=True)
+            sig = oracle.cigar_scan(reads, depth_len)
+            kind = sig["qpos_kind"] & 3
+            _same_sigs(out["sig_del"], sig[kind == 1]); _same_sigs(out["sig_ins"], sig[kind != 1])
+            assert np.array_equal(out["depth"], od) and (res.depth_sum, res.depth_nonzero) == (os_, onz)
+            mean = os_ / onz if onz else 0.0
+            min_pts = int(np.ceil(mean * pct)) if pct > 0 else 5
+            assert res.min_pts == min_pts
+            if min_pts >= 1:
+                dels, inss = sig[kind == 1], sig[kind != 1]
+                assert np.array_equal(out["label_del"], oracle.dbscan_iv(dels["start"], dels["end"], 0.1, min_pts))
+                assert np.array_equal(out["label_ins"], oracle.dbscan_iv(inss["start"], inss["end"], 0.1, min_pts))
+    finally:
+        sh.free()
