@@ -64,3 +64,40 @@ def test_seams_on_hostile_shards(ctx, oracle, seed, n_reads, depth_len, sorted_p
                 assert np.array_equal(out["label_ins"], oracle.dbscan_iv(inss["start"], inss["end"], 0.1, min_pts))
     finally:
         sh.free()
+
+
+def test_window_and_viterbi_on_extreme_values(ctx, oracle):
+    """Depth maps of zeros / 2^32-1, windows past the map, one-position regions, mean coverage 1e-300; observations of +-1e300,
+    BAF and population frequencies exactly 0 and 1: the kernels give the oracle's numbers (NaN and inf included)."""
+    from contextsv_amd import make_hmm
+    from hmm_params import WGS_HMM, WGS_TEST_HMM
+    rng = np.random.default_rng(11)
+    for it in range(16):
+        L = int(rng.choice([1, 2, 50, 1000, 200_000]))
+        depth = [rng.poisson(30, L), np.zeros(L, np.int64), rng.integers(0, 2**31, L), np.full(L, 2**32 - 1, np.int64)][it % 4].astype(np.uint32)
+        k = 10
+        rs = rng.integers(0, L + 50, k).astype(np.uint32)
+        re = (rs + rng.choice([0, 1, 5, 19, 20, 21, 1000, 10**6], k)).astype(np.uint32)
+        ss = rng.choice([1, 2, 5, 20, 137], k).astype(np.int32)
+        mean = float(rng.choice([29.7, 1e-300, 1.0, 1e6]))
+        l2, ws, we, off = ctx.window_log2(depth, rs, re, ss, mean)
+        for r in range(k):
+            o_l2, o_ws, o_we = oracle.window_log2(depth, int(rs[r]), int(re[r]), int(ss[r]), mean)
+            a, b = int(off[r]), int(off[r + 1])
+            assert np.array_equal(ws[a:b], o_ws) and np.array_equal(we[a:b], o_we)
+            np.testing.assert_allclose(l2[a:b], o_l2, rtol=0, atol=1e-6, equal_nan=True)
+    for params in (WGS_HMM, WGS_TEST_HMM):
+        hmm = make_hmm(**params)
+        o1s, o2s, pfs, off = [], [], [], [0]
+        for j in range(60):
+            T = int(rng.choice([0, 1, 2, 3, 20, 200, 1001]))
+            o1 = [rng.normal(0, 0.4, T), rng.choice([-50.0, -9.966, 0.0, 5.0, 50.0, 1e300, -1e300], T), np.zeros(T)][j % 3]
+            o1s.append(o1)
+            o2s.append(rng.choice([-1.0, 0.0, 1.0, 0.5, 1e-12, 1 - 1e-12, 0.3333], T))
+            pfs.append(rng.choice([0.0, 1.0, 0.5, 0.01, 0.99, 1e-9], T))
+            off.append(off[-1] + T)
+        o1, o2, pf = np.concatenate(o1s), np.concatenate(o2s), np.concatenate(pfs)
+        st, ll = ctx.viterbi(hmm, o1, o2, pf, np.asarray(off, np.uint64))
+        ost, oll = oracle.viterbi(hmm, o1, o2, pf, np.asarray(off, np.uint64))
+        assert np.array_equal(st, ost)
+        np.testing.assert_allclose(ll, oll, rtol=0, atol=1e-6, equal_nan=True)
