@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after the other (step latency)")
     ap.add_argument("--lanes", type=int, default=1, help="chromosomes in flight per GPU for the MAIN measurement (contexts with one stream "
                     "each, gated scan + depth phases); 1 keeps the kernel timings of the roofline free of co-running kernels")
+    ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timers around every kernel group, not only scan and depth")
     ap.add_argument("--no-two-lanes", action="store_true", help="skip the extra two-chromosomes-in-flight measurement")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0, help="fraction of the shard's reads given to the CPU baseline")
     args = ap.parse_args()
@@ -130,7 +131,7 @@ def main():
     if args.warmup:
         job(args.warmup)
     for c in lane_ctx:
-        c.timing_enable(True)
+        c.timing_enable(1 if args.time_all_kernels else 2)       # 2: events only around the two bandwidth-bound groups (each event idles the queue ~5 us)
         c.timing_reset()
     barrier()
     t0 = time.perf_counter()
@@ -163,6 +164,8 @@ def main():
             "sort": 16.0 * st.n_signatures * 2,
             "dbscan": 12.0 * st.n_signatures,
         }
+        for k in alg_bytes:
+            kern.setdefault(k, 0.0)
         dominant = max(alg_bytes.keys(), key=lambda k: kern.get(k, 0.0))
         ach = alg_bytes[dominant] / (kern[dominant] * 1e-3) / 1e9 if kern.get(dominant, 0) > 0 else 0.0
         traffic = None

@@ -174,7 +174,8 @@ class Context:
     def synchronize(self):
         self._check(self.lib.csvgpu_synchronize(self.h))
 
-    def timing_enable(self, on: bool = True):
+    def timing_enable(self, on=True):
+        """0 / False: off; 1 / True: HIP-event timers around every kernel group; 2: only around the CIGAR scan and the depth pass."""
         self._check(self.lib.csvgpu_timing_enable(self.h, int(on)))
 
     def timing_reset(self):

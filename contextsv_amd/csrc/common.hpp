@@ -50,7 +50,7 @@ struct csv_ctx {
     csv::Arena   work;                      // workspace sized after the signature count is known
     void        *pinned = nullptr;          // small pinned host block for scalar read-backs
     size_t       pinned_cap = 0;
-    bool         timing = false;
+    int          timing = 0;                // 0 off, 1 every kernel group, 2 only the two bandwidth-bound groups (scan, depth)
     std::vector<csv::Timer> timers;         // recorded, not yet folded
     std::vector<hipEvent_t> event_pool;
     double       t_ms[CSV_K_COUNT] = {0};
@@ -106,14 +106,15 @@ struct ScanCounters {
 
 int   arena_reserve(csv_ctx *ctx, Arena &a, size_t bytes);       // grow (sync + realloc) if needed, then reset
 void *arena_alloc(Arena &a, size_t bytes);                       // 256-B aligned slice, nullptr if exhausted
-void  timer_begin(csv_ctx *ctx, int id);
+bool  timer_begin(csv_ctx *ctx, int id);   // false: not recorded (timing off, or a group outside the selected level)
 void  timer_end(csv_ctx *ctx);
 int   ensure_pinned(csv_ctx *ctx, size_t bytes);
 
 struct TimerScope {
     csv_ctx *c;
-    TimerScope(csv_ctx *ctx, int id) : c(ctx) { timer_begin(c, id); }
-    ~TimerScope() { timer_end(c); }
+    bool on;
+    TimerScope(csv_ctx *ctx, int id) : c(ctx), on(timer_begin(c, id)) {}
+    ~TimerScope() { if (on) timer_end(c); }
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
