@@ -38,8 +38,8 @@ REC_I32 = 12                   # one merged call record = 48 B (host.CALL_DTYPE)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)      # 0.6 ms each: enough of them that filling and draining the pipeline do not show
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--chr-len", type=int, default=CHR22_LEN)
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--tech", choices=["ont", "hifi"], default="ont")

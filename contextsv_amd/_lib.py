@@ -70,6 +70,9 @@ ABI = {
     "csvgpu_shard_free": (None, [_P, _P]),
     "csvgpu_chr_pipeline_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.POINTER(csv_chr_result)]),
     "csvgpu_chr_pipeline_fetch": (C.c_int, [_P, _P, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.POINTER(csv_chr_result), _P, _P, C.c_uint64]),
+    "csvgpu_chr_job_begin": (_P, [_P, _P, C.c_uint32, C.c_uint8, C.c_double]),
+    "csvgpu_chr_job_cluster": (C.c_int, [_P, _P, C.c_double, _P, _P, C.c_uint64]),
+    "csvgpu_chr_job_end": (C.c_int, [_P, _P, C.POINTER(csv_chr_result)]),
     "csvgpu_gate_create": (_P, []),
     "csvgpu_gate_destroy": (None, [_P]),
     "csvgpu_set_gate": (C.c_int, [_P, _P]),

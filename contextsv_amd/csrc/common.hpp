@@ -60,6 +60,8 @@ struct csv_ctx {
     // csvgpu_host_alloc / csvgpu_host_free: page-locking is slow (hundreds of microseconds), so freed blocks are kept for reuse
     std::vector<std::pair<void *, size_t>> host_live, host_pool;
     csv_gate    *gate = nullptr;
+    char        *job_pin = nullptr;         // page-locked counter slots of the jobs in flight (csvgpu_chr_job_*)
+    size_t       job_pin_next = 0;
 };
 
 struct csv_shard {

@@ -358,6 +358,7 @@ void csvgpu_destroy(csv_ctx *ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->work.base) (void)hipFree(ctx->work.base);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->job_pin) (void)hipHostFree(ctx->job_pin);
     for (auto &b : ctx->host_pool) (void)hipHostFree(b.first);
     for (auto &b : ctx->host_live) (void)hipHostFree(b.first);       // blocks the caller never returned
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -913,70 +914,105 @@ void csvgpu_host_free(csv_ctx *ctx, void *p)
     }
 }
 
-static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct, csv_chr_result *res,
-                        csv_sig *host_sig, int32_t *host_labels, uint64_t capacity, bool fetch);
+// ---- one chromosome as a job in three steps, so that the caller can queue the scan + depth pass of the next chromosome before it
+// waits for this one's results (the device then never idles across the host's turn-around) ----
+struct csv_job {
+    csv_shard *sh = nullptr;
+    uint32_t min_oplen = 50; uint8_t min_mapq = 20; double min_pts_pct = 0.1;
+    hipEvent_t ev_mid = nullptr, ev_done = nullptr;
+    char *pin = nullptr;                 // 512 B page-locked: [0,256) counters behind the scan, [256,512) counters at the end
+    bool depth_queued = false, clustered = false, copied = false;
+    uint64_t n = 0, n_del = 0, capacity = 0;
+    csv_sig *sig_sorted = nullptr;
+    int32_t *labels = nullptr;
+};
 
-int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
-                            csv_chr_result *res)
+static char *job_pin_slot(csv_ctx *ctx)
 {
-    return chr_pipeline(ctx, sh, min_oplen, min_mapq, eps, min_pts_pct, res, nullptr, nullptr, 0, false);
+    constexpr size_t kSlots = 16, kSlot = 512;
+    if (!ctx->job_pin && hipHostMalloc((void **)&ctx->job_pin, kSlots * kSlot, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    char *p = ctx->job_pin + (ctx->job_pin_next % kSlots) * kSlot;
+    ctx->job_pin_next++;
+    return p;
 }
 
-int csvgpu_chr_pipeline_fetch(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
-                              csv_chr_result *res, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity)
+// scan + bucket counts (+ counters on their way to the host + depth pass, when the shard's sortedness is known)
+static int job_queue_front(csv_ctx *ctx, csv_job *job)
 {
-    if (capacity && (!host_sig || !host_labels)) { if (ctx) ctx->err = "pipeline_fetch: null output"; return CSV_EINVAL; }
-    return chr_pipeline(ctx, sh, min_oplen, min_mapq, eps, min_pts_pct, res, host_sig, host_labels, capacity, true);
+    csv_shard *sh = job->sh;
+    hipStream_t s = ctx->stream;
+    ScanCounters *cnt = (ScanCounters *)sh->counters;
+    int rc;
+    CSV_HIP(ctx, hipMemsetAsync(cnt, 0, kCntBytes, s));
+    // with a gate: this context's scan starts behind the previous holder's depth pass, and hands the turn on behind its own
+    csv_gate *gate = sh->unsorted >= 0 ? ctx->gate : nullptr;
+    std::unique_lock<std::mutex> turn;
+    if (gate) {
+        turn = std::unique_lock<std::mutex>(gate->mu);
+        if (gate->last) CSV_HIP(ctx, hipStreamWaitEvent(s, gate->last, 0));
+    }
+    {
+        TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
+        launch_cigar_scan(s, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
+                          sh->q_start, sh->q_end, sh->ckpt, cnt);
+    }
+    bucket_prepass(ctx, sh->sig_raw, sh->sig_cap, sh->depth_len, true, cnt);
+    job->depth_queued = false;
+    if (sh->unsorted >= 0) {
+        // The depth pass does not depend on the signature count, so it is queued BEFORE the host waits for the counters: the
+        // device works through it while the host wakes up, sizes the ordering and clustering launches and queues them.
+        CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, s));
+        CSV_HIP(ctx, hipEventRecord(job->ev_mid, s));
+        ctx->work.used = 0;
+        if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
+        launch_min_pts(s, cnt, job->min_pts_pct);
+        job->depth_queued = true;
+        if (gate) {
+            if (!gate->last) CSV_HIP(ctx, hipEventCreateWithFlags(&gate->last, hipEventDisableTiming));
+            CSV_HIP(ctx, hipEventRecord(gate->last, s));
+            turn.unlock();
+        }
+    }
+    return CSV_OK;
 }
 
-static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct, csv_chr_result *res,
-                        csv_sig *host_sig, int32_t *host_labels, uint64_t capacity, bool fetch)
+static void job_free(csv_ctx *ctx, csv_job *job)
 {
-    if (!ctx || !sh || !res) return CSV_EINVAL;
-    if (!(eps >= 0.0) || !(eps < 1.0)) { ctx->err = "pipeline: eps must be in [0,1)"; return CSV_EINVAL; }
+    if (!job) return;
+    if (job->ev_mid) ctx->event_pool.push_back(job->ev_mid);
+    if (job->ev_done) ctx->event_pool.push_back(job->ev_done);
+    delete job;
+}
+
+csv_job *csvgpu_chr_job_begin(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double min_pts_pct)
+{
+    if (!ctx || !sh) return nullptr;
     (void)hipSetDevice(ctx->device);
+    csv_job *job = new (std::nothrow) csv_job();
+    if (!job) { ctx->err = "out of host memory"; return nullptr; }
+    job->sh = sh; job->min_oplen = min_oplen; job->min_mapq = min_mapq; job->min_pts_pct = min_pts_pct;
+    job->ev_mid = get_event(ctx); job->ev_done = get_event(ctx);
+    job->pin = job_pin_slot(ctx);
+    if (!job->pin || !job->ev_mid || !job->ev_done) { ctx->err = "job: cannot allocate events / page-locked memory"; job_free(ctx, job); return nullptr; }
+    if (arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads, sh->depth_len)) || job_queue_front(ctx, job)) { job_free(ctx, job); return nullptr; }
+    return job;
+}
+
+int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity)
+{
+    if (!ctx || !job || job->clustered) return CSV_EINVAL;
+    if (!(eps >= 0.0) || !(eps < 1.0)) { ctx->err = "pipeline: eps must be in [0,1)"; return CSV_EINVAL; }
+    if (capacity && (!host_sig || !host_labels)) { ctx->err = "pipeline: null output"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    csv_shard *sh = job->sh;
     hipStream_t s = ctx->stream;
     ScanCounters *cnt = (ScanCounters *)sh->counters;
     ScanCounters h;
     int rc;
-    // The depth pass does not depend on the signature count, so when the shard's sortedness is already known it is queued behind
-    // the scan BEFORE the host waits for the counters: the device works through it while the host wakes up, sizes the ordering
-    // and clustering launches and queues them, instead of idling across the round trip.
-    if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads, sh->depth_len)))) return rc;
-    bool depth_queued = false;
     for (int attempt = 0;; attempt++) {
-        CSV_HIP(ctx, hipMemsetAsync(cnt, 0, kCntBytes, s));
-        // with a gate: this context's scan starts behind the previous holder's depth pass, and hands the turn on behind its own
-        csv_gate *gate = sh->unsorted >= 0 ? ctx->gate : nullptr;
-        std::unique_lock<std::mutex> turn;
-        if (gate) {
-            turn = std::unique_lock<std::mutex>(gate->mu);
-            if (gate->last) CSV_HIP(ctx, hipStreamWaitEvent(s, gate->last, 0));
-        }
-        {
-            TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
-            launch_cigar_scan(s, ctx->n_cu, sh->d, sh->depth_len, min_oplen, min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                              sh->q_start, sh->q_end, sh->ckpt, cnt);
-        }
-        bucket_prepass(ctx, sh->sig_raw, sh->sig_cap, sh->depth_len, true, cnt);
-        depth_queued = false;
-        if (sh->unsorted >= 0) {
-            if ((rc = ensure_pinned(ctx, 4096))) return rc;
-            CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, s));
-            hipEvent_t got = get_event(ctx);
-            CSV_HIP(ctx, hipEventRecord(got, s));
-            ctx->work.used = 0;
-            if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
-            launch_min_pts(s, cnt, min_pts_pct);
-            depth_queued = true;
-            if (gate) {
-                if (!gate->last) CSV_HIP(ctx, hipEventCreateWithFlags(&gate->last, hipEventDisableTiming));
-                CSV_HIP(ctx, hipEventRecord(gate->last, s));
-                turn.unlock();
-            }
-            CSV_HIP(ctx, wait_event(got));
-            ctx->event_pool.push_back(got);
-            memcpy(&h, ctx->pinned, sizeof(ScanCounters));
+        if (job->depth_queued) {
+            CSV_HIP(ctx, wait_event(job->ev_mid));
+            memcpy(&h, job->pin, sizeof(ScanCounters));
         } else {
             if ((rc = read_counters(ctx, cnt, h))) return rc;             // first scan of wrapped arrays: wait, then decide
             sh->unsorted = h.unsorted != 0;
@@ -987,13 +1023,13 @@ static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t
         CSV_HIP(ctx, hipFree(sh->sig_raw));
         sh->sig_raw = nullptr; sh->sig_cap = h.n_sig + h.n_sig / 8 + 1024;
         CSV_HIP(ctx, hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)));
+        if ((rc = job_queue_front(ctx, job))) return rc;
     }
-    const uint64_t n = h.n_sig, n_del = h.n_del, n_ins = n - n_del;
+    const uint64_t n = h.n_sig, n_del = h.n_del;
     const uint32_t max_bucket = h.max_len;
 
     // shard scratch: sorted signatures, SoA start/end, labels, sort + dbscan workspace (grow-only)
-    const uint64_t n_big = n;
-    const size_t need = align_up(n * sizeof(csv_sig), 256) + 3 * align_up(n * 4 + 16, 256) + sortws_bytes(n) + dbscan_tmp_bytes(n_big) + 4096;
+    const size_t need = align_up(n * sizeof(csv_sig), 256) + 3 * align_up(n * 4 + 16, 256) + sortws_bytes(n) + dbscan_tmp_bytes(n) + 4096;
     if (need > sh->scratch_cap) {
         if (sh->scratch) CSV_HIP(ctx, hipFree(sh->scratch));
         sh->scratch = nullptr; sh->scratch_cap = 0;
@@ -1006,14 +1042,14 @@ static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t
     int32_t *labels = (int32_t *)arena_alloc(sa, n * 4 + 16);
     SortWs w;
     const bool ws_ok = sortws_carve(sa, n, w);
-    void *db_tmp = arena_alloc(sa, dbscan_tmp_bytes(n_big));
+    void *db_tmp = arena_alloc(sa, dbscan_tmp_bytes(n));
     if (!sig_sorted || !st || !en || !labels || !ws_ok || !db_tmp) { ctx->err = "shard scratch exhausted"; return CSV_ENOMEM; }
 
-    // depth map + mean coverage + min_pts (device scalar), unless already queued above
-    if (!depth_queued) {
+    // depth map + mean coverage + min_pts (device scalar), unless already queued behind the scan
+    if (!job->depth_queued) {
         ctx->work.used = 0;
         if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
-        launch_min_pts(s, cnt, min_pts_pct);
+        launch_min_pts(s, cnt, job->min_pts_pct);
     }
 
     // ordering: DEL calls then INS calls, each in chr_sv_calls order
@@ -1025,19 +1061,63 @@ static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t
         // DEL calls [0, n_del) and INS calls [n_del, n) are clustered side by side in the same five launches
         if (n) launch_dbscan_iv_sorted(s, st, en, nullptr, n, n_del, eps, 0, &cnt->min_pts, labels, db_tmp);
     }
-    const bool copy_out = fetch && n && n <= capacity;
-    if (copy_out) {                                                      // results ride behind the last kernel, one wait for everything
+    job->copied = capacity && n && n <= capacity;
+    if (job->copied) {                                                   // results ride behind the last kernel, one wait for everything
         CSV_HIP(ctx, hipMemcpyAsync(host_sig, sig_sorted, n * sizeof(csv_sig), hipMemcpyDeviceToHost, s));
         CSV_HIP(ctx, hipMemcpyAsync(host_labels, labels, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     }
-    if ((rc = read_counters(ctx, cnt, h))) return rc;                     // final sync: scalars for the caller
-    res->n_sig = n; res->n_del = n_del; res->n_ins = n_ins;
-    res->depth_sum = h.depth_sum; res->depth_nonzero = h.depth_nonzero; res->min_pts = h.min_pts; res->mean_cov = h.mean_cov;
-    res->sig_del = sig_sorted; res->sig_ins = sig_sorted + n_del;
-    res->label_del = labels; res->label_ins = labels + n_del;
-    res->depth = sh->depth; res->ref_end = sh->ref_end; res->q_start = sh->q_start; res->q_end = sh->q_end;
-    if (fetch && n > capacity) { ctx->err = "pipeline_fetch: host buffers too small"; return CSV_ECAPACITY; }
+    CSV_HIP(ctx, hipMemcpyAsync(job->pin + 256, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipEventRecord(job->ev_done, s));
+    job->n = n; job->n_del = n_del; job->capacity = capacity; job->sig_sorted = sig_sorted; job->labels = labels;
+    job->clustered = true;
     return CSV_OK;
+}
+
+int csvgpu_chr_job_end(csv_ctx *ctx, csv_job *job, csv_chr_result *res)
+{
+    if (!ctx || !job) return CSV_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    int rc = CSV_OK;
+    if (!job->clustered) { ctx->err = "job_end before job_cluster"; rc = CSV_EINVAL; }
+    else if (wait_event(job->ev_done) != hipSuccess) { (void)hipGetLastError(); ctx->err = "job: device error"; rc = CSV_EHIP; }
+    else if (res) {
+        ScanCounters h;
+        memcpy(&h, job->pin + 256, sizeof(ScanCounters));
+        csv_shard *sh = job->sh;
+        res->n_sig = job->n; res->n_del = job->n_del; res->n_ins = job->n - job->n_del;
+        res->depth_sum = h.depth_sum; res->depth_nonzero = h.depth_nonzero; res->min_pts = h.min_pts; res->mean_cov = h.mean_cov;
+        res->sig_del = job->sig_sorted; res->sig_ins = job->sig_sorted + job->n_del;
+        res->label_del = job->labels; res->label_ins = job->labels + job->n_del;
+        res->depth = sh->depth; res->ref_end = sh->ref_end; res->q_start = sh->q_start; res->q_end = sh->q_end;
+        if (job->capacity && job->n > job->capacity) { ctx->err = "pipeline_fetch: host buffers too small"; rc = CSV_ECAPACITY; }
+    }
+    job_free(ctx, job);
+    return rc;
+}
+
+static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct, csv_chr_result *res,
+                        csv_sig *host_sig, int32_t *host_labels, uint64_t capacity)
+{
+    if (!ctx || !sh || !res) return CSV_EINVAL;
+    if (!(eps >= 0.0) || !(eps < 1.0)) { ctx->err = "pipeline: eps must be in [0,1)"; return CSV_EINVAL; }
+    csv_job *job = csvgpu_chr_job_begin(ctx, sh, min_oplen, min_mapq, min_pts_pct);
+    if (!job) return ctx->err.find("hipMalloc") != std::string::npos ? CSV_ENOMEM : CSV_EHIP;
+    const int rc = csvgpu_chr_job_cluster(ctx, job, eps, host_sig, host_labels, capacity);
+    if (rc) { job_free(ctx, job); return rc; }
+    return csvgpu_chr_job_end(ctx, job, res);
+}
+
+int csvgpu_chr_pipeline_dev(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
+                            csv_chr_result *res)
+{
+    return chr_pipeline(ctx, sh, min_oplen, min_mapq, eps, min_pts_pct, res, nullptr, nullptr, 0);
+}
+
+int csvgpu_chr_pipeline_fetch(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
+                              csv_chr_result *res, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity)
+{
+    if (capacity && (!host_sig || !host_labels)) { if (ctx) ctx->err = "pipeline_fetch: null output"; return CSV_EINVAL; }
+    return chr_pipeline(ctx, sh, min_oplen, min_mapq, eps, min_pts_pct, res, host_sig, host_labels, capacity);
 }
 
 }  // extern "C"

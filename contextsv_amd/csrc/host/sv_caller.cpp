@@ -164,36 +164,87 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
     const size_t n = shards.size();
     calls.assign(n, {});
     stats.assign(n, ChrStats());
-    DeviceOut slot[2];                                    // double buffer between the device thread and the merge thread
+    // The representative choice of one chromosome (~0.5 ms for chr22: a sequential selection over the noise bucket) takes about as
+    // long as its device chain, so two merge threads take alternate chromosomes; three result slots rotate between the device
+    // thread (filling one) and the two merges in progress.
+    constexpr size_t kMergers = 2, kSlots = kMergers + 1;
+    DeviceOut slot[kSlots];
     std::mutex mu;
     std::condition_variable cv;
-    size_t produced = 0, consumed = 0;                    // shards handed over / merged
+    std::vector<char> ready(n, 0), merged(n, 0);          // guarded by mu
+    bool failed = false;
     std::exception_ptr worker_err;
-    std::thread worker([&] {
-        try {
-            for (size_t i = 0; i < n; i++) {
-                { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return produced > i || produced == SIZE_MAX; }); if (produced == SIZE_MAX) return; }
-                hostMerge("shard" + std::to_string(i), slot[i & 1], seq, calls[i], stats[i]);
-                { std::lock_guard<std::mutex> l(mu); consumed = i + 1; }
+    std::vector<std::thread> workers;
+    for (size_t w = 0; w < kMergers; w++) {
+        workers.emplace_back([&, w] {
+            try {
+                for (size_t i = w; i < n; i += kMergers) {
+                    { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return ready[i] || failed; }); if (failed) return; }
+                    hostMerge("shard" + std::to_string(i), slot[i % kSlots], seq, calls[i], stats[i]);
+                    { std::lock_guard<std::mutex> l(mu); merged[i] = 1; }
+                    cv.notify_all();
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> l(mu);
+                if (!worker_err) worker_err = std::current_exception();
+                failed = true;
                 cv.notify_all();
             }
-        } catch (...) { worker_err = std::current_exception(); std::lock_guard<std::mutex> l(mu); consumed = SIZE_MAX; cv.notify_all(); }
-    });
+        });
+    }
+    auto stop_workers = [&] {
+        { std::lock_guard<std::mutex> l(mu); failed = true; }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    };
+    csv_job *ahead = nullptr;                             // the job whose scan + depth pass is already queued
     try {
+        if (n) {
+            ahead = csvgpu_chr_job_begin(ctx, shards[0], (uint32_t)min_oplen, (uint8_t)min_mapq, pct);
+            if (!ahead) throw std::runtime_error(std::string("processChromosome: ") + csvgpu_last_error(ctx));
+        }
         for (size_t i = 0; i < n; i++) {
-            // slot i&1 is free once shard i-2 has been merged
-            { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return consumed == SIZE_MAX || consumed + 2 > i; }); if (consumed == SIZE_MAX) break; }
-            runDeviceChain("shard" + std::to_string(i), shards[i], eps, pct, slot[i & 1], stats[i]);
-            { std::lock_guard<std::mutex> l(mu); produced = i + 1; }
+            // slot i % kSlots is free once shard i - kSlots has been merged
+            if (i >= kSlots) {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return merged[i - kSlots] || failed; });
+                if (failed) break;
+            }
+            const double t0 = now_ms();
+            DeviceOut &out = slot[i % kSlots];
+            ChrStats &st = stats[i];
+            if (!out.cap) out.reserve(ctx, 1 << 16);
+            csv_job *job = ahead;
+            ahead = nullptr;
+            int rc = csvgpu_chr_job_cluster(ctx, job, eps, out.sig, out.lab, out.cap);
+            if (rc) { csvgpu_chr_job_end(ctx, job, nullptr); check(ctx, rc, "processChromosome"); }
+            // the next shard's scan + depth pass go into the queue now, behind this shard's clustering and copies: the device
+            // does not wait for the host's turn-around (result wait, hand-over to a merge thread, next call)
+            if (i + 1 < n) {
+                ahead = csvgpu_chr_job_begin(ctx, shards[i + 1], (uint32_t)min_oplen, (uint8_t)min_mapq, pct);
+                if (!ahead) { csvgpu_chr_job_end(ctx, job, nullptr); throw std::runtime_error(std::string("processChromosome: ") + csvgpu_last_error(ctx)); }
+            }
+            csv_chr_result res;
+            rc = csvgpu_chr_job_end(ctx, job, &res);
+            if (rc == CSV_ECAPACITY) {                     // first contig of this size: grow the buffers, fetch what the device still holds
+                out.reserve(ctx, res.n_sig);
+                rc = csvgpu_chr_fetch(ctx, shards[i], &res, out.sig, out.lab);
+            }
+            check(ctx, rc, "processChromosome");
+            st.n_signatures = res.n_sig; st.n_del = res.n_del; st.n_ins = res.n_ins;
+            st.depth_sum = res.depth_sum; st.depth_nonzero = res.depth_nonzero; st.mean_chr_cov = res.mean_cov; st.dbscan_min_pts = res.min_pts;
+            out.n_del = res.n_del; out.n_ins = res.n_ins;
+            st.ms_device = now_ms() - t0;
+            { std::lock_guard<std::mutex> l(mu); ready[i] = 1; }
             cv.notify_all();
         }
+        if (ahead) { csvgpu_chr_job_end(ctx, ahead, nullptr); ahead = nullptr; }      // only after a merge-thread failure cut the loop short
     } catch (...) {
-        { std::lock_guard<std::mutex> l(mu); produced = SIZE_MAX; }
-        cv.notify_all();
-        worker.join();
+        if (ahead) csvgpu_chr_job_end(ctx, ahead, nullptr);
+        stop_workers();
         throw;
     }
-    worker.join();
+    for (auto &t : workers) t.join();
     if (worker_err) std::rethrow_exception(worker_err);
 }
 

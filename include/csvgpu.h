@@ -236,6 +236,20 @@ int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *shard, const csv_chr_result *resul
 int csvgpu_chr_pipeline_fetch(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct,
                               csv_chr_result *result, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity);
 
+/* The same per-chromosome path as a job in three steps, for callers that keep the device busy across their own turn-around:
+ *   begin   queues the CIGAR scan, the bucket counts and (for shards whose sortedness is known) the depth pass;
+ *   cluster waits for the signature count, queues ordering + DBSCAN and the copies into host_sig / host_labels (capacity records
+ *           each; page-locked memory from csvgpu_host_alloc) — and returns without waiting;
+ *   end     waits for the job, fills *result, frees the job; CSV_ECAPACITY when the host buffers were too small (the results
+ *           are then on the device: csvgpu_chr_fetch).
+ * Between cluster(i) and end(i) the caller may begin(i + 1) on the same context — also on the same shard, everything being
+ * ordered by the context's stream: the next chromosome's scan then starts on the device the moment this one's last copy is done.
+ * csvgpu_chr_pipeline_fetch is begin + cluster + end. */
+typedef struct csv_job csv_job;
+csv_job *csvgpu_chr_job_begin(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, uint8_t min_mapq, double min_pts_pct);
+int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity);
+int csvgpu_chr_job_end(csv_ctx *ctx, csv_job *job, csv_chr_result *result);
+
 /* Several contexts on one GPU (one per host thread, each with its own stream) keep several chromosomes in flight. A gate makes
  * their bandwidth-bound phases (CIGAR scan + depth pass) take turns on the device — ordered with events, no host blocking — while
  * the latency-bound tail of one chromosome (ordering, clustering, copies, host wake-ups) overlaps the scan of the next. The
