@@ -48,10 +48,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-file", action="store_true", help="skip the BAM-staged from-file measurement")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after the other (step latency)")
-    ap.add_argument("--lanes", type=int, default=1, help="chromosomes in flight per GPU for the MAIN measurement (contexts with one stream "
-                    "each, gated scan + depth phases); 1 keeps the kernel timings of the roofline free of co-running kernels")
+    ap.add_argument("--lanes", type=int, default=2, help="chromosomes in flight per GPU (contexts with one stream each, gated scan + depth "
+                    "phases); kernel durations stretch by a few per cent under co-running kernels, the throughput gains ~20 %%")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timers around every kernel group, not only scan and depth")
-    ap.add_argument("--no-two-lanes", action="store_true", help="skip the extra two-chromosomes-in-flight measurement")
+    ap.add_argument("--no-two-lanes", action="store_true", help="skip the extra measurement with the other lane count (1 <-> 2)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0, help="fraction of the shard's reads given to the CPU baseline")
     args = ap.parse_args()
 
@@ -209,6 +209,8 @@ def main():
         }
         if world == 1 and n_lanes == 1 and not args.no_pipeline and not args.no_two_lanes:
             out["two_lanes"] = two_lanes(cs, host, dev, ctx, shard, reads, depth_len, args)
+        if world == 1 and n_lanes > 1 and not args.no_two_lanes:
+            out["one_lane"] = one_lane(host, ctx, shard, reads, args)
         if world == 1 and not args.no_from_file:
             out["from_file"] = from_file(ctx, syn, args, st)
         if world == 1 and not args.no_cpu_baseline:
@@ -255,6 +257,18 @@ def two_lanes(cs, host, dev, ctx, shard, reads, depth_len, args):
             sh2.free()
         ctx2.close()
         gate.close()
+
+
+def one_lane(host, ctx, shard, reads, args):
+    """The same K steps with a single chromosome in flight (one context, one stream): what the lanes add."""
+    if args.warmup:
+        host.process_resident_pipelined(ctx, shard, max(args.warmup, 2), args.eps, args.min_pts_pct, capacity=GATHER_CAP)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    host.process_resident_pipelined(ctx, shard, args.steps, args.eps, args.min_pts_pct, capacity=GATHER_CAP)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": reads.n_reads * args.steps / el, "unit": "reads/s", "ms_per_step": el / args.steps * 1e3, "lanes": 1, "steps": args.steps}
 
 
 def from_file(ctx, syn, args, st):
