@@ -484,7 +484,7 @@ class BamFile:
             ln = lib.csvhost_bam_shard_qnames(self.h, i, None, 0)
             buf = C.create_string_buffer(max(int(ln), 1))
             lib.csvhost_bam_shard_qnames(self.h, i, buf, ln)
-            out["qnames"] = buf.raw[:ln].decode().split("\n")[:-1]
+            out["qnames"] = buf.raw[:ln].decode(errors="replace").split("\n")[:-1]
         return out
 
     def read_contig(self, chr: str, want_seq=False, want_qnames=False, threads=8, window_blocks=0):
