@@ -40,3 +40,44 @@ def test_lanes_give_the_single_context_result(ctx):
         ctx2.close()
         gate.close()
         syn_a.free(); syn_b.free()
+
+
+def test_pipelined_driver_grows_result_buffers_and_matches_single_calls(ctx):
+    """More signatures than the driver's initial page-locked buffers hold (first contig of that size: CSV_ECAPACITY -> grow ->
+    csvgpu_chr_fetch while the next job's scan is already queued), several steps on the same shard, against the one-shot call."""
+    M, D = 0, 2
+    n_reads, per = 3000, 40                                # 120 000 signatures > the initial 65 536 + slack
+    pos = np.sort(np.random.default_rng(4).integers(0, 150_000, n_reads))
+    cig = [[op for k in range(per) for op in ((M, 90 + (r + k) % 7), (D, 50 + (r * 7 + k) % 40))] + [(M, 50)] for r in range(n_reads)]
+    reads = cs.Reads.from_cigar_lists(pos, np.zeros(n_reads, np.uint16), np.full(n_reads, 60, np.uint8), cig)
+    sh = ctx.upload(reads, 170_000)
+    try:
+        want, _, st1 = host.process_resident_chromosome(ctx, sh, 0.1, 0.1)
+        got, _, st, ms, total = host.process_resident_pipelined(ctx, sh, 5, 0.1, 0.1)
+        assert st.n_signatures == st1.n_signatures == n_reads * per
+        assert got.tobytes() == want.tobytes() and total == 5 * len(want) and len(want) > 0
+    finally:
+        sh.free()
+
+
+def test_job_calls_out_of_order(ctx):
+    import ctypes as C
+    from contextsv_amd._lib import csv_chr_result
+    syn = host.SynthShard(seed=3, chr_len=500_000, depth=5.0, tech=0, threads=2)
+    sh = ctx.upload(syn.reads, syn.depth_len)
+    lib = ctx.lib
+    try:
+        job = lib.csvgpu_chr_job_begin(ctx.h, sh.h, 50, 20, 0.1)
+        assert job
+        res = csv_chr_result()
+        assert lib.csvgpu_chr_job_end(ctx.h, job, C.byref(res)) == cs._lib.CSV_EINVAL          # end before cluster: refused, job released
+        job = lib.csvgpu_chr_job_begin(ctx.h, sh.h, 50, 20, 0.1)
+        assert lib.csvgpu_chr_job_cluster(ctx.h, job, 1.5, None, None, 0) == cs._lib.CSV_EINVAL   # eps outside [0, 1)
+        assert lib.csvgpu_chr_job_cluster(ctx.h, job, 0.1, None, None, 0) == 0
+        assert lib.csvgpu_chr_job_cluster(ctx.h, job, 0.1, None, None, 0) == cs._lib.CSV_EINVAL   # twice
+        assert lib.csvgpu_chr_job_end(ctx.h, job, C.byref(res)) == 0 and res.n_sig > 0
+        ref = sh.pipeline()
+        assert (ref.n_sig, ref.depth_sum, ref.min_pts) == (res.n_sig, res.depth_sum, res.min_pts)
+    finally:
+        sh.free()
+        syn.free()
