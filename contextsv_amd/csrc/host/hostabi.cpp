@@ -603,6 +603,47 @@ int csvhost_synth_write_bam(const csvhost_synth *h, const char *path, const char
     })
 }
 
+// Several synthetic shards into ONE coordinate-sorted BAM + BAI, one contig each, appended in tid order.
+struct csvhost_bam_writer { BamWriter w; };
+csvhost_bam_writer *csvhost_bam_writer_open(const char *path, int n_ref, const char *ref_names, const uint32_t *ref_lens, int level, int threads)
+{
+    try {
+        BamHeader hd;
+        hd.text = "@HD\tVN:1.6\tSO:coordinate\n";
+        const char *p = ref_names;
+        for (int i = 0; i < n_ref; i++) {
+            const char *e = strchr(p, '\n');
+            hd.names.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+            hd.lens.push_back(ref_lens[i]);
+            hd.text += "@SQ\tSN:" + hd.names.back() + "\tLN:" + std::to_string(ref_lens[i]) + "\n";
+            p = e ? e + 1 : p + strlen(p);
+        }
+        csvhost_bam_writer *h = new csvhost_bam_writer();
+        if (!h->w.open(path, hd, level, threads)) { g_err = h->w.error(); delete h; return nullptr; }
+        return h;
+    } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+int csvhost_bam_writer_append_synth(csvhost_bam_writer *h, const csvhost_synth *syn, int tid)
+{
+    GUARD({
+        const SynthShard &sh = syn->sh;
+        for (size_t i = 0; i < sh.pos.size(); i++) {
+            if (i && sh.pos[i] < sh.pos[i - 1]) throw std::runtime_error("synthetic shard is not coordinate-sorted");
+            h->w.add(tid, sh.pos[i], sh.mapq[i], sh.flag[i], "r" + std::to_string(tid) + "_" + std::to_string(i), sh.cigar.data() + sh.cigar_off[i],
+                     (uint32_t)(sh.cigar_off[i + 1] - sh.cigar_off[i]), nullptr, 0, nullptr);
+        }
+    })
+}
+int csvhost_bam_writer_close(csvhost_bam_writer *h)
+{
+    GUARD({
+        const bool ok = h->w.close();
+        const std::string e = h->w.error();
+        delete h;
+        if (!ok) throw std::runtime_error(e);
+    })
+}
+
 struct csvhost_bam_stats { uint64_t n_contigs, n_reads, n_cigar, bam_bytes; double ms_decode, ms_total; };
 
 // SVCaller::runBam: chrs = '\n'-separated contig names or null (all). SNPs: none (every window gets the dummy observation).

@@ -109,6 +109,10 @@ def load() -> C.CDLL:
     lib.csvhost_gnomad_contig.argtypes = [C.c_char_p, C.c_char_p, _P, C.c_uint64]
     lib.csvhost_process_resident_lanes.argtypes = [C.c_int, _P, _P, _P, C.c_double, C.c_double, _P, C.c_uint64, C.POINTER(chr_stats),
                                                    C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.csvhost_bam_writer_open.restype = _P
+    lib.csvhost_bam_writer_open.argtypes = [C.c_char_p, C.c_int, C.c_char_p, _P, C.c_int, C.c_int]
+    lib.csvhost_bam_writer_append_synth.argtypes = [_P, _P, C.c_int]
+    lib.csvhost_bam_writer_close.argtypes = [_P]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -579,3 +583,21 @@ def gnomad_contig(chr: str, pfb_path_: str) -> str:
     buf = C.create_string_buffer(4096)
     n = load().csvhost_gnomad_contig(chr.encode(), pfb_path_.encode(), buf, 4096)
     return buf.raw[:n].decode()
+
+
+class SynthBamWriter:
+    """Several SynthShards into one coordinate-sorted BAM + BAI, one contig each (append in contig order)."""
+
+    def __init__(self, path: str, ref_names, ref_lens, level: int = 1, threads: int = 8):
+        lens = np.ascontiguousarray(ref_lens, np.uint32)
+        self.h = load().csvhost_bam_writer_open(os.fsencode(path), len(ref_names), "\n".join(ref_names).encode(), lens.ctypes.data, level, threads)
+        if not self.h:
+            raise RuntimeError((load().csvhost_last_error() or b"cannot create BAM").decode())
+
+    def append(self, syn: SynthShard, tid: int):
+        _check(load().csvhost_bam_writer_append_synth(self.h, syn.h, tid))
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, None
+            _check(load().csvhost_bam_writer_close(h))

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--contigs", type=int, default=24)
     ap.add_argument("--scale", type=float, default=1.0, help="scale every contig length (quick runs)")
+    ap.add_argument("--one-bam", action="store_true", help="all contigs in ONE BAM and one runBam call: contig i + 1 is decoded while contig i is on "
+                    "the device, every shard stays resident until the copy-number pass at the end")
     args = ap.parse_args()
     import contextsv_amd as cs
     from contextsv_amd import host
@@ -38,7 +40,26 @@ def main():
     tot = {"reads": 0, "cigar_ops": 0, "bam_bytes": 0, "calls": 0, "stage_s": 0.0, "run_s": 0.0, "decode_wait_s": 0.0}
     per = []
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
-        for k in range(min(args.contigs, 24)):
+        if args.one_bam:
+            n = min(args.contigs, 24)
+            lens = [int(GRCH38[k] * args.scale) for k in range(n)]
+            bam = os.path.join(d, "genome.bam")
+            t0 = time.perf_counter()
+            w = host.SynthBamWriter(bam, NAMES[:n], lens, level=1, threads=args.threads)
+            for k in range(n):
+                syn = host.SynthShard(0x5EED0000 + 1000 * 1 + k + 1, lens[k], args.depth, 0, args.threads)
+                w.append(syn, k)
+                tot["reads"] += syn.reads.n_reads; tot["cigar_ops"] += syn.reads.n_cigar
+                syn.free()
+                print(NAMES[k], "staged", file=sys.stderr, flush=True)
+            w.close()
+            t1 = time.perf_counter()
+            calls, tids, bs = host.run_bam(ctx, bam, hmm, threads=args.threads, split_svs=False, cigar_cn=True, capacity=1 << 22)
+            t2 = time.perf_counter()
+            tot["bam_bytes"] = os.path.getsize(bam); tot["calls"] = len(calls)
+            tot["stage_s"] = t1 - t0; tot["run_s"] = t2 - t1; tot["decode_wait_s"] = bs["ms_decode"] * 1e-3
+            per = [{"contig": NAMES[k], "calls": int((tids == k).sum())} for k in range(n)]
+        for k in range(0 if args.one_bam else min(args.contigs, 24)):
             length = int(GRCH38[k] * args.scale)
             t0 = time.perf_counter()
             syn = host.SynthShard(0x5EED0000 + 1000 * 1 + k + 1, length, args.depth, 0, args.threads)
@@ -54,8 +75,9 @@ def main():
             tot["stage_s"] += t1 - t0; tot["run_s"] += t2 - t1; tot["decode_wait_s"] += bs["ms_decode"] * 1e-3
             per.append({"contig": NAMES[k], "reads": int(n_reads), "run_s": round(t2 - t1, 3), "calls": int(len(calls))})
             print(NAMES[k], n_reads, "reads", "%.2f s staged, %.3f s run, %d calls" % (t1 - t0, t2 - t1, len(calls)), file=sys.stderr, flush=True)
-    out = {"workload": "GRCh38 primary contig lengths x %.2f, %gx synthetic ONT, one BAM per contig, runBam (CIGAR + depth + DBSCAN + mergeSVs + CIGAR CN pass)"
+    out = {"workload": "GRCh38 primary contig lengths x %.2f, %gx synthetic ONT, runBam (CIGAR + depth + DBSCAN + mergeSVs + CIGAR CN pass)"
                        % (args.scale, args.depth),
+           "layout": "one BAM, one runBam call" if args.one_bam else "one BAM per contig, one runBam call each",
            "n_contigs": len(per), "inflate_threads": args.threads, **{k: (round(v, 3) if isinstance(v, float) else int(v)) for k, v in tot.items()},
            "reads_per_s_from_file": tot["reads"] / tot["run_s"], "per_contig": per}
     print(json.dumps(out))
