@@ -16,39 +16,60 @@ enum : uint16_t { FLAG_UNMAP = 0x4, FLAG_REVERSE = 0x10, FLAG_SECONDARY = 0x100,
 struct PrimaryAlignment { int start, end, query_start, query_end; bool strand; int cluster_size; };   // sv_caller.h:33-40
 struct SuppAlignment { int tid, start, end, query_start, query_end; bool strand; };                  // sv_caller.h:42-49
 
-// the reference's unbalanced BST keyed by start with a max_end annotation (sv_caller.cpp:948-980); nodes are inserted
-// in the iteration order of the qname hash map, and the pre-order walk of findOverlaps is the group's member order
-struct IntervalNode {
-    PrimaryAlignment region;
-    const std::string *qname;
-    int max_end;
-    std::unique_ptr<IntervalNode> left, right;
-    IntervalNode(const PrimaryAlignment &r, const std::string *q) : region(r), qname(q), max_end(r.end) {}
+// The reference's unbalanced BST keyed by start with a max_end annotation (sv_caller.cpp:948-980): nodes are inserted in the
+// iteration order of the qname hash map, and the pre-order walk of findOverlaps is a group's member order, so the SHAPE of the tree
+// is part of the result. libstdc++ iterates a freshly filled map roughly in reverse insertion order, i.e. by descending start for
+// a coordinate-sorted BAM: the tree degenerates into a spine, insertion is quadratic (0.9 s for 2e5 primaries) and the reference's
+// recursive insert / findOverlaps recurse once per node. The same shape is built here in O(n log n): the tree a sequence of
+// BST insertions produces is the Cartesian tree of the keys (start, insertion index) with the insertion index as heap priority.
+struct IntervalTree {
+    struct Node { PrimaryAlignment region; const std::string *qname; int max_end; int32_t left, right; };
+    std::vector<Node> nodes;                     // in insertion order
+    int32_t root = -1;
+
+    void add(const PrimaryAlignment &r, const std::string *q) { nodes.push_back(Node{r, q, r.end, -1, -1}); }
+
+    void build()
+    {
+        const int32_t n = (int32_t)nodes.size();
+        std::vector<int32_t> order((size_t)n);
+        for (int32_t i = 0; i < n; i++) order[(size_t)i] = i;
+        // equal starts go to the right of the earlier node (`region.start < root->region.start` else right, :969-975)
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return nodes[(size_t)a].region.start != nodes[(size_t)b].region.start ? nodes[(size_t)a].region.start < nodes[(size_t)b].region.start : a < b;
+        });
+        std::vector<int32_t> spine;              // right spine of the tree built so far, insertion indices increasing
+        for (int32_t i : order) {
+            int32_t last = -1;
+            while (!spine.empty() && spine.back() > i) { last = spine.back(); spine.pop_back(); }
+            nodes[(size_t)i].left = last;
+            if (!spine.empty()) nodes[(size_t)spine.back()].right = i;
+            spine.push_back(i);
+        }
+        root = spine.empty() ? -1 : spine.front();
+        for (int32_t i = n - 1; i >= 0; i--) {   // children were inserted later than their parent: their maxima are final
+            Node &x = nodes[(size_t)i];
+            if (x.left >= 0) x.max_end = std::max(x.max_end, nodes[(size_t)x.left].max_end);
+            if (x.right >= 0) x.max_end = std::max(x.max_end, nodes[(size_t)x.right].max_end);
+        }
+    }
+
+    // findOverlaps: node, then left (if it can overlap), then right, on an explicit stack
+    void overlaps(const PrimaryAlignment &q, std::vector<const std::string *> &out, std::vector<int32_t> &stack) const
+    {
+        stack.clear();
+        if (root >= 0) stack.push_back(root);
+        while (!stack.empty()) {
+            const Node &n = nodes[(size_t)stack.back()];
+            stack.pop_back();
+            if (q.start <= n.region.end && q.end >= n.region.start) out.push_back(n.qname);
+            // The reference always descends to the right (:961). Subtrees that cannot hold an overlap contribute nothing, so skipping
+            // them keeps the result and its order: right descendants all start at or after this node, and max_end bounds every end.
+            if (n.right >= 0 && n.region.start <= q.end && nodes[(size_t)n.right].max_end >= q.start) stack.push_back(n.right);
+            if (n.left >= 0 && nodes[(size_t)n.left].max_end >= q.start) stack.push_back(n.left);
+        }
+    }
 };
-
-void tree_insert(std::unique_ptr<IntervalNode> &root, const PrimaryAlignment &region, const std::string *qname)
-{
-    std::unique_ptr<IntervalNode> *cur = &root;          // iterative: hash order can still produce long spines
-    while (*cur) {
-        IntervalNode *n = cur->get();
-        cur = region.start < n->region.start ? &n->left : &n->right;
-        n->max_end = std::max(n->max_end, region.end);
-    }
-    *cur = std::make_unique<IntervalNode>(region, qname);
-}
-
-void tree_overlaps(const IntervalNode *root, const PrimaryAlignment &q, std::vector<const std::string *> &out)
-{
-    // explicit stack, same visiting order as the recursive form: node, then left (if it can overlap), then right
-    std::vector<const IntervalNode *> stack;
-    if (root) stack.push_back(root);
-    while (!stack.empty()) {
-        const IntervalNode *n = stack.back(); stack.pop_back();
-        if (q.start <= n->region.end && q.end >= n->region.start) out.push_back(n->qname);
-        if (n->right) stack.push_back(n->right.get());
-        if (n->left && n->left->max_end >= q.start) stack.push_back(n->left.get());
-    }
-}
 
 // DBSCAN1D::getLargestCluster on precomputed labels (dbscan1d.cpp:72-90)
 std::vector<int> largest_cluster(const std::vector<int> &points, const std::vector<int> &labels)
@@ -114,15 +135,18 @@ void findSplitSVSignatures(const std::vector<SplitRecord> &records, const std::v
         printMessage("Processing chromosome " + chr_name + " with " + std::to_string(chr_primary_map.size()) + " primary alignments");
 
         // ---- overlap groups (:215-238): direct overlaps of the first unprocessed read in hash order, not transitive ----
-        std::unique_ptr<IntervalNode> root;
-        for (const auto &entry : chr_primary_map) tree_insert(root, entry.second, &entry.first);
+        IntervalTree tree;
+        tree.nodes.reserve(chr_primary_map.size());
+        for (const auto &entry : chr_primary_map) tree.add(entry.second, &entry.first);
+        tree.build();
         std::vector<std::vector<const std::string *>> primary_clusters;
         {
             std::set<std::string> processed;
+            std::vector<int32_t> walk;
             for (const auto &entry : chr_primary_map) {
                 if (processed.find(entry.first) != processed.end()) continue;
                 std::vector<const std::string *> group;
-                tree_overlaps(root.get(), entry.second, group);
+                tree.overlaps(entry.second, group, walk);
                 for (const std::string *q : group) processed.insert(*q);
                 if (group.size() > 1) primary_clusters.push_back(std::move(group));
             }
