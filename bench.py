@@ -67,11 +67,21 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # CSV_BENCH_REHEARSE=1: rehearsal of the N>1 driver logic on a box with fewer cards than ranks — gloo instead of RCCL,
+        # ranks share the cards round-robin, collectives on host tensors. Never the judged configuration.
+        rehearse = os.environ.get("CSV_BENCH_REHEARSE") == "1"
+        if rehearse:
+            local_rank %= torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
+        rehearse = False
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    coll_dev = torch.device("cpu") if rehearse else dev
 
     # ---- synthetic shard: seed = 0x5EED0000 + 1000*config + chr_index ------------
     tech = 0 if args.tech == "ont" else 1
@@ -118,7 +128,7 @@ def main():
         if world > 1:
             # every step re-runs the same shard, so the job's call set is n_steps copies of `calls`
             per_shard = {rank * 1000 + k: calls[: GATHER_CAP // 8] for k in range(min(n_steps, 32))}
-            parallel.gather_calls(per_shard, cap=GATHER_CAP * 4, dist=dist, device=dev)     # fixed 1.5 MB buffer per rank
+            parallel.gather_calls(per_shard, cap=GATHER_CAP * 4, dist=dist, device=coll_dev)     # fixed 1.5 MB buffer per rank
         return calls, st
 
     def barrier():
@@ -145,8 +155,8 @@ def main():
             timing[k] = (a[0] + ms, a[1] + n)
         c.timing_enable(False)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(reads.n_reads), float(st.n_signatures), float(reads.n_cigar)], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    tot = torch.tensor([float(reads.n_reads), float(st.n_signatures), float(reads.n_cigar)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)

@@ -146,6 +146,13 @@ static int check_reads(csv_ctx *ctx, const csv_reads *r)
         ctx->err = "csv_reads: null array"; return CSV_EINVAL;
     }
     if (r->n_reads >= 0xffffffffull) { ctx->err = "csv_reads: more than 2^32-2 reads in one shard"; return CSV_EINVAL; }
+    // the kernels index the word array with these offsets: nothing reaches the device unless they are monotone and inside it
+    // (a read's own word count stays far below 2^31: the scan works in 32-bit read-relative indices)
+    for (uint64_t i = 0; i < r->n_reads; i++) {
+        if (r->cigar_off[i + 1] < r->cigar_off[i]) { ctx->err = "csv_reads: cigar_off not monotone"; return CSV_EINVAL; }
+        if (r->cigar_off[i + 1] - r->cigar_off[i] >= 0x7ffff000ull) { ctx->err = "csv_reads: a read with 2^31 CIGAR words"; return CSV_EINVAL; }
+    }
+    if (r->cigar_off[r->n_reads] > r->n_cigar) { ctx->err = "csv_reads: cigar_off beyond n_cigar"; return CSV_EINVAL; }
     return CSV_OK;
 }
 

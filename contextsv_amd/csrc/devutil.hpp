@@ -103,4 +103,10 @@ __device__ __forceinline__ bool iv_neighbor(uint32_t s1, uint32_t e1, uint32_t s
     return (1.0 - mn) <= eps;
 }
 
+// A value every lane holds alike, moved to scalar registers: hipcc cannot prove that what comes out of LDS or of a load is
+// wave-uniform, and without the hint a loop nest driven by such values (scan.hip's read / chunk loops) is compiled as divergent control flow (exec-mask loops,
+// 64-bit VALU compares) — a third of that walk's VALU instructions.
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) { return ((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v); }
+
 }  // namespace csv

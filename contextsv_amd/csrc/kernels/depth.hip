@@ -254,14 +254,14 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         const uint32_t n_items = wl_n;
         const int32_t TW = (int32_t)(T1 - T0);                                      // tile width in positions
         for (uint32_t it = depth_grab(&next_item, lane); it < n_items; it = depth_grab(&next_item, lane)) {
-            const uint64_t chunk0 = wl_chunk[it];
-            const int32_t c0rel = wl_c0rel[it];
-            const uint32_t nrem = wl_nrem[it];
+            const uint64_t chunk0 = uniform64(wl_chunk[it]);                        // `it` is wave-uniform: keep the item in scalar registers
+            const int32_t c0rel = (int32_t)uniform32((uint32_t)wl_c0rel[it]);
+            const uint32_t nrem = uniform32(wl_nrem[it]);
             // Positions are kept relative to the tile's left edge in 32-bit signed arithmetic (coordinates and run lengths are
             // below 2^31, the BAM limit): a run [rel, rel + len) clips to [max(rel,0), min(rel+len, TW)) with one max and one min,
             // and a run with no aligned bases (len masked to 0) clips to nothing, so no separate op test is needed.
-            int32_t base_rel = (int32_t)(wl_p1[it] + wl_carry[it] - (uint32_t)T0);  // wave-uniform: first staged word of the chunk
-            uint32_t w[4], w1[4];
+            int32_t base_rel = (int32_t)uniform32(wl_p1[it] + wl_carry[it] - (uint32_t)T0);  // wave-uniform: first staged word of the chunk
+            uint32_t w[4], w1[4] = {0, 0, 0, 0};
             const bool whole0 = vec_ok && chunk0 + 4 * WAVE <= n_cigar;
             if (whole0) { const uint4 v = *reinterpret_cast<const uint4 *>(cigar + chunk0 + (uint64_t)lane * 4); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
             else depth_load4(cigar, n_cigar, vec_ok, chunk0 + (uint64_t)lane * 4, w);
@@ -283,9 +283,10 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                 uint32_t rl[4], al[4], lane_ref = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t op = w[k] & 15u, len = w[k] >> 4;
-                    rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)REF_OPS, op, 1u);    // all-ones when the op consumes the reference
-                    al[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)ALN_OPS, op, 1u);    // ... when its bases count toward depth
+                    // v_bfe_i32 takes its bit offset from the word's low five bits (op + the length's lowest bit): op masks repeated at bit 16
+                    const uint32_t len = w[k] >> 4;
+                    rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), w[k], 1u);    // all-ones when the op consumes the reference
+                    al[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(ALN_OPS | (ALN_OPS << 16)), w[k], 1u);    // ... when its bases count toward depth
                     lane_ref += rl[k];
                 }
                 const uint32_t incl = wave_incl_sum_dpp(lane_ref);
@@ -300,10 +301,8 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                     rel += (int32_t)rl[k];
                 }
                 base_rel += (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (more) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) w[k] = w1[k];
-                }
+                for (int k = 0; k < 4; k++) w[k] = w1[k];                           // (stale when !more: the loop ends there)
             }
         }
         __syncthreads();

@@ -3,11 +3,17 @@
 // Replaces SVCaller::findCIGARSVs / processCIGARRecord (sv_caller.cpp:506-661) and
 // getAlignmentReadPositions + bam_endpos (sv_caller.cpp:663-690) for one shard of reads.
 //
-// One 64-lane wave owns one read at a time. Each lane takes 4 consecutive packed CIGAR words
-// (one 16-byte load, 1 KiB per wave instruction, aligned by starting at cigar_off & ~255 and
-// masking the words that belong to the neighbouring reads), a wave prefix sum turns op lengths
-// into reference / query cursors, and ops with len >= min_oplen of kind I / S / D become 16-byte
-// signatures. Signatures are rare (~1e-3 of ops) so they are staged in a per-workgroup LDS buffer
+// One 64-lane wave owns one read at a time. Each lane takes 4 consecutive packed CIGAR words of a 1 KiB chunk (chunks are aligned
+// to 256 words; the words of a boundary chunk that belong to the neighbouring reads are masked), a wave prefix sum turns op
+// lengths into reference / query cursors, and ops with len >= min_oplen of kind I / S / D become 16-byte signatures.
+//
+// The CIGAR words reach the wave through a per-wave LDS ring filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+// instruction, no VGPR destination). A wave's reads are contiguous in the word array, so its loads are one sequential stream of
+// chunks; RING_D chunks are kept in flight per wave at no register cost (one chunk ahead in registers left the walk bound by
+// load latency x occupancy: 6 waves/SIMD x 1 KiB in flight), and a chunk shared by two reads is fetched once and read twice
+// from LDS (it used to be fetched per read: +22 % load instructions at 1.1 k words per read).
+//
+// Signatures are rare (~1e-3 of ops) so they are staged in a per-workgroup LDS buffer
 // (slots reserved with an LDS compare-and-swap) and flushed with ONE global atomic per workgroup;
 // a single hot global counter would otherwise serialise the chip. Emission order is arbitrary —
 // the ordering pass (sort.hip) reproduces the reference's addSVCall order afterwards.
@@ -21,31 +27,50 @@ namespace csv {
 
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
-constexpr uint32_t CAND_OPS = (1u << OP_I) | (1u << OP_D) | (1u << OP_S);
-constexpr uint32_t SIG_BUF = 1024;           // signatures staged per workgroup (16 KiB LDS)
+constexpr uint32_t SIG_BUF = 512;            // signatures staged per workgroup (8 KiB LDS); more go straight to HBM
+constexpr int RING_D = 4;                    // 1 KiB chunks in flight per wave (16 KiB LDS per workgroup)
+constexpr int SCAN_OCC = 6;                  // workgroups per CU the LDS allows. 8 (RING_D 3, SIG_BUF 256) measured the same: the walk is
+                                             // bound by instruction issue (VALU 60 %, scalar unit 57 % busy), not by latency or occupancy
+constexpr int CHUNK_WORDS = 4 * WAVE;
 
 struct Chunk {
     uint32_t w[4];
 };
 
-// `base` = first word of the 1 KiB chunk (wave-uniform), lane l takes words base + 4l .. base + 4l + 3. Only the last chunk of
-// the whole array can be partial, so the bounds test is done once per wave, not per lane.
-__device__ __forceinline__ Chunk load_chunk(const uint32_t *__restrict__ cigar, uint64_t base, int lane, uint64_t n_cigar, int vec_ok)
+// LDS-DMA: lane l's 16 bytes at gbase + lane_byte_off land at lds_dst + 16 l (lds_dst wave-uniform, carried in M0). hipcc does not count an asm
+// load in its own s_waitcnt bookkeeping, which is the point: the consumer waits with a counted vmcnt (ring_wait) instead of the
+// vmcnt(0) hipcc puts in front of every LDS read while a __builtin_amdgcn_global_load_lds is outstanding.
+__device__ __forceinline__ void glds16(const uint32_t *gbase, uint32_t lane_byte_off, uint32_t lds_dst)      // gbase, lds_dst wave-uniform
 {
-    Chunk c;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_off), "s"(gbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p; }
+
+// Fill one ring slot with the chunk starting at word `base` (wave-uniform, multiple of 256). Only the last chunk of the whole
+// array can be partial (or the base pointer unaligned, never for our own uploads): those go through registers, padded with P ops.
+__device__ __forceinline__ void ring_issue(uint32_t *slot, const uint32_t *__restrict__ cigar, uint64_t base, int lane, uint64_t n_cigar, int vec_ok)
+{
     const uint64_t idx = base + (uint64_t)lane * 4;
-    if (vec_ok && base + 4 * WAVE <= n_cigar) {
-        uint4 v = *reinterpret_cast<const uint4 *>(cigar + idx);
-        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
-    } else if (vec_ok && idx + 4 <= n_cigar) {
-        uint4 v = *reinterpret_cast<const uint4 *>(cigar + idx);
-        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+    if (vec_ok && base + CHUNK_WORDS <= n_cigar) {
+        glds16(cigar + base, (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(slot)));
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) c.w[k] = (idx + k < n_cigar) ? cigar[idx + k] : (uint32_t)OP_P;
+        for (int k = 0; k < 4; k++) slot[lane * 4 + k] = (idx + k < n_cigar) ? cigar[idx + k] : (uint32_t)OP_P;
     }
-    return c;
 }
+
+// Loads return in issue order, so "at most RING_D - 1 vector-memory operations outstanding" means the DMA issued RING_D - 1
+// fills ago has landed (stores in between only make the wait more conservative).
+__device__ __forceinline__ void ring_wait_steady()
+{
+    static_assert(RING_D >= 2 && RING_D <= 4, "add the immediate for RING_D - 1");
+    if (RING_D == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (RING_D == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (RING_D == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+}
+__device__ __forceinline__ void ring_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // first read index r in [0, n] with cigar_off[r] >= target (cigar_off is non-decreasing); 64-ary search by one wave
 __device__ __forceinline__ uint64_t wave_lower_bound(const uint64_t *__restrict__ cigar_off, uint64_t n, uint64_t target, int lane)
@@ -74,7 +99,6 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t i)
 {
     return ((uint64_t)bcast32((uint32_t)(v >> 32), i) << 32) | bcast32((uint32_t)v, i);
 }
-
 struct ScanMd {
     uint64_t c0, c1;
     uint32_t p0, fl, mq, unsorted;
@@ -93,9 +117,8 @@ __device__ __forceinline__ ScanMd scan_load_md(uint64_t r, uint64_t n_reads, con
     return m;
 }
 
-// 6 waves/SIMD (80 VGPRs, a dozen spilled dwords on the signature path) instead of 5 at the natural 95: the walk is bound by
-// occupancy
-__global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
+// 54 VGPRs; the LDS (ring + signature buffer) sets the occupancy
+__global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint8_t *__restrict__ mapq, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
     int vec_ok, uint32_t depth_len, uint32_t start_limit, uint32_t min_oplen, uint32_t min_mapq, int emit,
@@ -103,11 +126,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
     int32_t *__restrict__ q_end, uint32_t *__restrict__ ckpt, ScanCounters *__restrict__ cnt)
 {
     __shared__ csv_sig buf[SIG_BUF];
+    __shared__ uint32_t ring[SCAN_WAVES][RING_D][CHUNK_WORDS];
     __shared__ uint32_t buf_n, blk_n_del, blk_direct, blk_overflow;
     __shared__ unsigned long long blk_gbase;
 
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = (int)uniform32(threadIdx.x >> 6);
     if (threadIdx.x == 0) { buf_n = 0; blk_n_del = 0; blk_direct = 0; blk_overflow = 0; }
     // (the __syncthreads() after the split-point search below also publishes these)
 
@@ -132,12 +156,18 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
         }
     }
     __syncthreads();
-    const uint64_t r_begin = split_s[wave];
-    const uint64_t r_end = split_s[wave + 1];
+    const uint64_t r_begin = uniform64(split_s[wave]);
+    const uint64_t r_end = uniform64(split_s[wave + 1]);
+
+    // This wave's load stream: the chunks [ring_base, ring_base + 256 ring_total) cover its reads' words.
+    const uint64_t ring_base = uniform64((r_begin < r_end ? cigar_off[r_begin] : 0) & ~(uint64_t)(CHUNK_WORDS - 1));
+    const uint32_t ring_total = uniform32(r_begin < r_end ? (uint32_t)((cigar_off[r_end] - ring_base + CHUNK_WORDS - 1) / CHUNK_WORDS) : 0u);
+    uint32_t ring_ready = 0;              // chunks [0, ring_ready) have landed; chunks [ring_ready, ring_ready + RING_D - 1) are in flight
+    for (uint32_t a = 0; a < (uint32_t)(RING_D - 1) && a < ring_total; a++)
+        ring_issue(ring[wave][a], cigar, ring_base + (uint64_t)a * CHUNK_WORDS, lane, n_cigar, vec_ok);
 
     // Per-read metadata is loaded for 64 reads at a time, lane-parallel and coalesced (lane l <-> read rb + l), and handed to
-    // the wave with readlane; a wave's whole share is usually one batch. Inside the read loop only CIGAR chunk loads remain:
-    // the next read's first chunk is requested when the current read reaches its last chunk.
+    // the wave with readlane; a wave's whole share is usually one batch. Inside the read loop only the ring traffic remains.
     for (uint64_t rb = r_begin; rb < r_end; rb += WAVE) {
     const uint64_t nb_reads = min((uint64_t)WAVE, r_end - rb);
     uint64_t l_c0 = 0; uint32_t l_p0 = 0, l_flmq = 0, l_uns = 0;     // lane l: first CIGAR word, pos, flag | mapq << 16 of read rb + l
@@ -148,9 +178,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
         l_p0 = (uint32_t)p; l_flmq = (uint32_t)flag[rr] | ((uint32_t)mapq[rr] << 16);
         l_uns = (rr > 0 && p < pos[rr - 1]) ? 1u : 0u;
     }
-    const uint64_t batch_end_word = cigar_off[rb + nb_reads];        // wave-uniform
+    const uint64_t batch_end_word = uniform64(cigar_off[rb + nb_reads]);
     if (__ballot(l_uns != 0) && lane == 0) cnt->unsorted = 1u;
-    Chunk first = load_chunk(cigar, bcast64(l_c0, 0) & ~255ull, lane, n_cigar, vec_ok);
     for (uint32_t ri = 0; ri < (uint32_t)nb_reads; ri++) {
         const uint64_t r = rb + ri;
         const bool have_next = ri + 1 < (uint32_t)nb_reads;
@@ -159,8 +188,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
         const uint32_t p0 = bcast32(l_p0, ri);
         const uint32_t flmq = bcast32(l_flmq, ri);
         const uint32_t fl = flmq & 0xffffu, mq = flmq >> 16;
-        const uint64_t next_base = c1 & ~255ull;
-        bool next_first_issued = false;
         // sv_caller.cpp:526
         const bool emit_ok = emit && !(fl & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && mq >= min_mapq;
 
@@ -171,40 +198,58 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
         uint32_t ref_carry = 0;      // reference bases consumed before this chunk (wave-uniform)
         uint32_t acc_q = 0;          // this lane's share of the query bases consumed before this chunk
         uint32_t acc_skip = 0;       // this lane's share of soft clips skipped by the `continue` at sv_caller.cpp:602-604
-        int32_t  qs = -1;            // query_start
+        int32_t  qs = -1;            // query_start (wave-uniform, kept in a scalar register)
 
+        // Chunks are aligned to 256 words (1 KiB; a chunk boundary is a checkpoint slot). Inside a read everything is 32-bit and
+        // relative to its first word (csv_reads validation bounds a read's word count): chunk t of the read holds the
+        // read-relative words [256 t - head, 256 t - head + 256).
         const uint32_t n_words = (uint32_t)(c1 - c0);
-        const uint64_t base = c0 & ~255ull;       // chunks are aligned to 256 words (1 KiB): a chunk boundary is a checkpoint slot
-        int32_t rel = (int32_t)(base - c0) + lane * 4;   // index of this lane's first word relative to the read's first word
-        Chunk cur = first;
-        for (uint64_t chunk = base; chunk < c1; chunk += 4 * WAVE, rel += 4 * WAVE) {
-            Chunk nxt;
-            const bool more = chunk + 4 * WAVE < c1;
-            if (more) nxt = load_chunk(cigar, chunk + 4 * WAVE, lane, n_cigar, vec_ok);   // prefetch next 1 KiB
-            else if (have_next) {                                                                        // last chunk: next read's first
-                first = load_chunk(cigar, next_base, lane, n_cigar, vec_ok);
-                next_first_issued = true;
+        const uint32_t head = (uint32_t)c0 & (uint32_t)(CHUNK_WORDS - 1);          // words of the first chunk that belong to earlier reads
+        const uint32_t n_chunks = n_words ? (head + n_words + CHUNK_WORDS - 1) / CHUNK_WORDS : 0u;
+        const uint32_t j0 = (uint32_t)((c0 - head - ring_base) / CHUNK_WORDS);     // the first chunk's index in this wave's stream
+        uint32_t *__restrict__ const ck_read = ckpt + ((c0 - head) >> CKPT_SHIFT);
+        int32_t rel = lane * 4 - (int32_t)head;          // index of this lane's first word relative to the read's first word
+        for (uint32_t t = 0; t < n_chunks; t++, rel += CHUNK_WORDS) {
+            // chunk j of the stream: top the ring up (chunks before j are dead, so slots (j, j + RING_D) mod RING_D are free), wait for j
+            const uint32_t j = j0 + t;
+            if (j == ring_ready) {                // first visit (chunks are visited in stream order; a boundary chunk is visited again by the next read)
+                const uint32_t ahead = j + (RING_D - 1);
+                if (ahead < ring_total) {
+                    ring_issue(ring[wave][ahead % RING_D], cigar, ring_base + (uint64_t)ahead * CHUNK_WORDS, lane, n_cigar, vec_ok);
+                    ring_wait_steady();           // chunks j + 1 .. j + RING_D - 1 may still be in flight
+                } else {
+                    ring_wait_all();
+                }
+                ring_ready = j + 1;
+            }
+            Chunk cur;
+            {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&ring[wave][j % RING_D][lane * 4]);
+                cur.w[0] = v.x; cur.w[1] = v.y; cur.w[2] = v.z; cur.w[3] = v.w;
             }
 
             // only the first and the last chunk of a read can hold words of its neighbours: mask those to a no-op (P, length 0)
-            if (!(chunk >= c0 && chunk + 4 * WAVE <= c1)) {
+            const bool edge = (t == 0 && head != 0) || (t + 1) * CHUNK_WORDS - head > n_words;
+            if (edge) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) if (!((uint32_t)(rel + k) < n_words)) cur.w[k] = (uint32_t)OP_P;   // also catches rel + k < 0
             }
             uint32_t len[4], op[4], rl[4], ql[4];
-            uint32_t lane_ref = 0, lane_q = 0, max_cand = 0, qst = 0;
+            uint32_t lane_ref = 0, lane_q = 0, trig = 0, qst = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                op[k] = cur.w[k] & 15u;
+                op[k] = cur.w[k] & 15u;                  // (only the slow paths read op[])
                 len[k] = cur.w[k] >> 4;
-                rl[k] = len[k] & (uint32_t)__builtin_amdgcn_sbfe((int)REF_OPS, op[k], 1u);     // all-ones mask when the op consumes the reference
-                ql[k] = len[k] & (uint32_t)__builtin_amdgcn_sbfe((int)QRY_OPS, op[k], 1u);
+                // all-ones mask when the op consumes the reference / the query. v_bfe_i32 takes its bit offset from the low FIVE bits
+                // of the word — the op and the length's lowest bit — so the op masks are repeated in the upper half-word.
+                rl[k] = len[k] & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), cur.w[k], 1u);
+                ql[k] = len[k] & (uint32_t)__builtin_amdgcn_sbfe((int)(QRY_OPS | (QRY_OPS << 16)), cur.w[k], 1u);
                 lane_ref += rl[k];
                 lane_q += ql[k];
-                max_cand = max(max_cand, len[k] & (uint32_t)__builtin_amdgcn_sbfe((int)CAND_OPS, op[k], 1u));   // only I / D / S ops can become signatures
+                trig |= rl[k] ^ ql[k];                   // the length of an op that consumes exactly one of the two: I, S, D (and N)
             }
-            // a conservative trigger for the slow path, which re-tests every op exactly
-            const uint32_t big = max_cand >= min_oplen ? 1u : 0u;
+            // a conservative trigger for the slow path, which re-tests every op exactly: an OR is at least its largest operand
+            const bool big = trig >= min_oplen;
             if (qs < 0) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) qst |= (QST_OPS >> op[k]) & 1u;
@@ -212,10 +257,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
             const uint32_t incl_ref = wave_incl_sum_dpp(lane_ref);
             {   // checkpoints: the reference offset of this read at every CKPT_WORDS-th word strictly inside it (depth.hip starts its
                 // walks there); one store instruction per chunk, lanes 0, 16, 32, 48
-                const uint64_t w = chunk + (uint64_t)lane * 4;
-                if ((lane & (CKPT_WORDS / 4 - 1)) == 0 && w > c0 && w < c1) ckpt[w >> CKPT_SHIFT] = ref_carry + (incl_ref - lane_ref);
+                static_assert(CKPT_WORDS == 64, "one checkpoint per DPP row of 16 lanes x 4 words");
+                uint32_t *__restrict__ ck = ck_read + t * (CHUNK_WORDS / CKPT_WORDS);
+                const bool inside = (edge || t == 0) ? (rel > 0 && (uint32_t)rel < n_words) : true;       // wave-uniform choice of the test
+                if ((lane & 15) == 0 && inside) ck[lane >> 4] = ref_carry + (incl_ref - lane_ref);
             }
-            const bool need_q = (qs < 0) || (emit_ok && __ballot(big != 0) != 0);
+            const bool any_big = emit_ok && __ballot(big) != 0;
+            const bool need_q = (qs < 0) || any_big;
             if (need_q) {
                 // ---------------- slow path: query cursors --------------------------------------------------
                 const uint32_t q_carry = wave_total_dpp(acc_q);
@@ -234,11 +282,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
                             if (!found && ((QST_OPS >> op[k]) & 1u)) { found = true; q_at = acc; }
                             acc += ql[k];
                         }
-                        qs = (int32_t)__shfl(q_at, __ffsll((long long)m) - 1, 64);
+                        qs = (int32_t)bcast32(q_at, (uint32_t)(__ffsll((long long)m) - 1));
                     }
                 }
 
-                if (emit_ok && __ballot(big != 0) != 0) {
+                if (any_big) {
                     // candidate ops: len >= min_oplen and I / S / D (sv_caller.cpp:566-643)
                     uint32_t cand = 0, skipped = 0, lane_skip = 0;
                     {
@@ -309,9 +357,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
             }
             acc_q += lane_q;
             ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)incl_ref, 63);
-            if (more) cur = nxt;
         }
-        if (have_next && !next_first_issued) first = load_chunk(cigar, next_base, lane, n_cigar, vec_ok);
 
         const uint32_t q_total = wave_total_dpp(acc_q);
         if (lane == 0) {
@@ -324,7 +370,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void cigar_scan_kernel(
         }
     }
     }
-
+    ring_wait_all();        // nothing may still be in flight towards this workgroup's LDS when it retires
 
     if (!emit) return;
     // workgroup epilogue: ONE global atomic per workgroup reserves the output range of the LDS buffer (the DEL count rides
@@ -371,7 +417,7 @@ void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t dep
         blocks_per_cu = occ;
     }
     uint64_t want = (d.n_reads + SCAN_WAVES - 1) / SCAN_WAVES;
-    // two rounds of workgroups measured best (0.237 vs 0.247 ms at one round: the second round evens out the tail)
+    // two rounds of workgroups measured best (0.177 ms; 0.191 at one round, 0.179 at three to four, 0.192 at six)
     uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 2;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;

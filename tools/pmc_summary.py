@@ -23,7 +23,31 @@ def summarise(directory, counter):
     return {k: {"launches": n, "mean_KB": s / n} for k, (n, s) in acc.items()}
 
 
+def summarise_all(directory):
+    """every counter found under `directory`: {kernel: {counter: mean per launch}} for the kernels that matter"""
+    acc = {}
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        per = {}
+        for row in csv.DictReader(open(path)):
+            key = (row.get("Dispatch_Id"), row.get("Kernel_Name", "").split("(")[0], row.get("Counter_Name"))
+            per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+        for (_, name, counter), v in per.items():
+            a = acc.setdefault(name, {}).setdefault(counter, [0, 0.0])
+            a[0] += 1
+            a[1] += v
+    return {k: {c: s / n for c, (n, s) in d.items()} for k, d in acc.items()}
+
+
 if __name__ == "__main__":
+    if sys.argv[2] == "--all":
+        out = summarise_all(sys.argv[3])
+        json.dump(out, open(sys.argv[1], "w"), indent=1)
+        for k, d in out.items():
+            if "scan" in k or "depth_tile" in k:
+                print(k)
+                for c, v in sorted(d.items()):
+                    print("   %-32s %.4g" % (c, v))
+        sys.exit(0)
     out = {}
     for spec in sys.argv[2:]:
         counter, directory = spec.split("=", 1)
