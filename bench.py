@@ -38,7 +38,7 @@ REC_I32 = 12                   # one merged call record = 48 B (host.CALL_DTYPE)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)      # 0.6 ms each: enough of them that filling and draining the pipeline do not show
+    ap.add_argument("--steps", type=int, default=400)      # ~0.45 ms each: enough of them that filling and draining the three lanes do not show
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--chr-len", type=int, default=CHR22_LEN)
     ap.add_argument("--depth", type=float, default=30.0)
@@ -48,8 +48,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-file", action="store_true", help="skip the BAM-staged from-file measurement")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after the other (step latency)")
-    ap.add_argument("--lanes", type=int, default=2, help="chromosomes in flight per GPU (contexts with one stream each, gated scan + depth "
-                    "phases); kernel durations stretch by a few per cent under co-running kernels, the throughput gains ~20 %%")
+    ap.add_argument("--lanes", type=int, default=3, help="chromosomes in flight per GPU (contexts sharing a gate: their scan + depth pairs run back "
+                    "to back on the gate's stream, their small kernels beside them); the big kernels stretch by ~10 %% under the co-running "
+                    "small ones, the throughput gains ~25 %% over one lane; four lanes are slower again")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timers around every kernel group, not only scan and depth")
     ap.add_argument("--no-two-lanes", action="store_true", help="skip the extra measurement with the other lane count (1 <-> 2)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0, help="fraction of the shard's reads given to the CPU baseline")
@@ -241,10 +242,9 @@ def main():
 
 
 def two_lanes(cs, host, dev, ctx, shard, reads, depth_len, args):
-    """Two chromosomes in flight on the GPU: a second context (own stream) with its own resident copy of the contig, the scan +
-    depth phases of the two taking turns through a gate, the latency-bound tail of one overlapping the scan of the other. Same
-    K steps, same work per step; kernel durations stretch a little under co-running kernels, which is why the main `value` and
-    the roofline are taken with one lane."""
+    """Two chromosomes in flight on the GPU (the extra leg of a --lanes 1 run): a second context with its own resident copy of the
+    contig, the scan + depth pairs of the two back to back on the gate's stream, the small kernels of one beside the pair of the
+    other. Same K steps, same work per step."""
     ctx2 = cs.Context(dev.index)
     gate = cs.Gate()
     sh2 = None
@@ -270,7 +270,8 @@ def two_lanes(cs, host, dev, ctx, shard, reads, depth_len, args):
 
 
 def one_lane(host, ctx, shard, reads, args):
-    """The same K steps with a single chromosome in flight (one context, one stream): what the lanes add."""
+    """The same K steps with a single chromosome in flight (one context, one stream, no gate): what the lanes add."""
+    ctx.set_gate(None)
     if args.warmup:
         host.process_resident_pipelined(ctx, shard, max(args.warmup, 2), args.eps, args.min_pts_pct, capacity=GATHER_CAP)
     ctx.synchronize()

@@ -27,6 +27,7 @@ constexpr uint32_t QST_OPS = (1u << OP_M) | (1u << OP_I) | (1u << OP_EQ) | (1u <
 struct Timer {
     hipEvent_t a, b;
     int id;
+    hipStream_t s;
 };
 
 struct Arena {                     // grow-only bump allocator over one device buffer; reset per entry point
@@ -38,13 +39,15 @@ struct Arena {                     // grow-only bump allocator over one device b
 
 // turn-taking of the bandwidth-bound phases of several contexts on one device (csvgpu_gate_*)
 struct csv_gate {
-    std::mutex mu;
-    hipEvent_t last = nullptr;          // recorded behind the most recent scan + depth phase of any attached context
+    std::mutex  mu;                     // held while a context queues its scan + depth pair
+    hipStream_t stream = nullptr;       // the ONE stream the attached contexts' big kernels run on, back to back
+    int         device = -1;
 };
 
 struct csv_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
+    hipStream_t  side = nullptr;            // carries the counters to the host beside the depth pass (jobs)
     bool         own_stream = false;
     csv::Arena   arena;                     // staged inputs / outputs of the host-pointer entry points
     csv::Arena   work;                      // workspace sized after the signature count is known
@@ -78,7 +81,9 @@ struct csv_shard {
     int32_t  *labels = nullptr;
     uint32_t *ord = nullptr;       // read permutation by pos when the shard is not coordinate-sorted
     char     *scratch = nullptr;   size_t scratch_cap = 0;   // sort / dbscan workspace
-    uint64_t *counters = nullptr;  // device scalars (see ScanCounters)
+    uint64_t *counters = nullptr;  // device scalars (see ScanCounters) + bucket tables + the depth tiles' candidate ranges, zeroed together per chromosome
+    uint64_t *tile_range = nullptr;   // inside `counters`
+    size_t    counters_bytes = 0;
 };
 
 namespace csv {
@@ -90,7 +95,7 @@ struct ScanCounters {
     unsigned long long depth_sum;
     unsigned int       depth_nonzero;
     unsigned int       max_start;    // 0xffffffff if a signature start exceeded scan_start_limit(depth_len), else 0
-    unsigned int       max_len;      // largest bucket of the ordering pass's most-significant-digit split (bk_prep_kernel)
+    unsigned int       max_len;      // largest bucket of the ordering pass's most-significant-digit split (scan epilogue)
     unsigned int       unsorted;     // != 0 if pos[] is not non-decreasing
     int                min_pts;      // written by the min_pts kernel
     int                pad;
@@ -108,14 +113,14 @@ struct ScanCounters {
 
 int   arena_reserve(csv_ctx *ctx, Arena &a, size_t bytes);       // grow (sync + realloc) if needed, then reset
 void *arena_alloc(Arena &a, size_t bytes);                       // 256-B aligned slice, nullptr if exhausted
-bool  timer_begin(csv_ctx *ctx, int id);   // false: not recorded (timing off, or a group outside the selected level)
+bool  timer_begin(csv_ctx *ctx, int id, hipStream_t s = nullptr);   // false: not recorded (timing off, or a group outside the selected level); s: the stream the group runs on (default: the context's)
 void  timer_end(csv_ctx *ctx);
 int   ensure_pinned(csv_ctx *ctx, size_t bytes);
 
 struct TimerScope {
     csv_ctx *c;
     bool on;
-    TimerScope(csv_ctx *ctx, int id) : c(ctx), on(timer_begin(c, id)) {}
+    TimerScope(csv_ctx *ctx, int id, hipStream_t s = nullptr) : c(ctx), on(timer_begin(c, id, s)) {}
     ~TimerScope() { if (on) timer_end(c); }
 };
 
@@ -126,19 +131,33 @@ static inline int bits_of(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } r
 // launchers implemented in kernels/*.hip (all asynchronous on `s`)
 
 // scan.hip
+// What the scan can produce on the side for the passes behind it, so that nothing small has to run between the big kernels:
+struct ScanExtras {
+    uint64_t *tile_range = nullptr;   // [2 * n_tiles], zeroed: candidate read range of every depth tile (see DEPTH_TILE below); coordinate-sorted shards only
+    uint32_t  n_tiles = 0;
+    uint32_t *bucket_hist = nullptr;  // [BK_N], zeroed: counts of the ordering pass's most-significant-digit buckets; the largest goes to cnt->max_len
+    int       type_pos = -1, bucket_shift = 0;
+};
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
-                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt);
+                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &extras = ScanExtras());
+void launch_validate_offsets(hipStream_t s, const uint64_t *cigar_off, uint64_t n_reads, uint64_t n_cigar, uint64_t max_words, uint32_t *bad /* zeroed; set to 1 */);
 uint32_t scan_start_limit(uint32_t depth_len);   // exclusive bound on signature starts that the ordering keys are sized for
 // depth.hip
 void launch_prefix_max(hipStream_t s, const int32_t *in, int32_t *out, uint64_t n, void *tmp /* >= 4 KiB + n/1024*4 */);
 size_t prefix_max_tmp_bytes(uint64_t n);
-// ord == nullptr: reads are coordinate-sorted and pos_s == d.pos; otherwise pos_s / pmax_end are in ord order.
-// ckpt: reference offset of the owning read at every 256-word CIGAR boundary (written by launch_cigar_scan).
-void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *pos_s,
-                        const int32_t *ref_end, const int32_t *pmax_end, const uint32_t *ckpt, uint32_t depth_len,
-                        uint32_t *depth, ScanCounters *cnt, void *tmp /* depth_tiles_tmp_bytes(depth_len) */);
+// One workgroup of the depth pass owns DEPTH_TILE positions. tile_range[2t] = ~(first candidate read), tile_range[2t + 1] = one past
+// the last: all-zero means "no read" and both halves are maintained with atomicMax, by the scan itself (ScanExtras) or by
+// launch_depth_ranges.
+constexpr int DEPTH_TILE_SHIFT = 14, DEPTH_TILE = 1 << DEPTH_TILE_SHIFT;
+static inline uint32_t depth_n_tiles(uint32_t depth_len) { return (uint32_t)(((uint64_t)depth_len + DEPTH_TILE - 1) / DEPTH_TILE); }
 size_t depth_tiles_tmp_bytes(uint32_t depth_len);
+// ranges from a prefix maximum of the read ends, for shards whose ranges the scan did not produce (unsorted: in `ord` order)
+void launch_depth_ranges(hipStream_t s, const int32_t *pos_s, const int32_t *pmax_end, uint64_t n_reads, uint32_t depth_len, uint64_t *tile_range);
+// ord == nullptr: reads are coordinate-sorted; otherwise the tile ranges index `ord`.
+// ckpt: reference offset of the owning read at every CKPT_WORDS-word CIGAR boundary (written by launch_cigar_scan).
+void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *ref_end, const uint32_t *ckpt,
+                        uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range);
 // reference-offset checkpoints every CKPT_WORDS CIGAR words (scan.hip writes them, depth.hip starts its walks from them)
 constexpr int CKPT_SHIFT = 6, CKPT_WORDS = 1 << CKPT_SHIFT;
 static inline size_t ckpt_bytes(uint64_t n_cigar) { return ((n_cigar >> CKPT_SHIFT) + 2) * sizeof(uint32_t); }
@@ -152,8 +171,8 @@ int  launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, 
                            uint64_t n, int key_bits, void *tmp);
 // bucket ordering: BK_N most-significant-digit buckets + one wave ranking each bucket; see sort.hip
 constexpr uint32_t BK_BITS = 14, BK_N = 1u << BK_BITS, BK_LOCAL_MAX = 2048;
-void launch_bucket_hist(hipStream_t s, const csv_sig *sig, ScanCounters *cnt, uint64_t cap, int type_pos, int shift, uint32_t *hist, uint32_t *cur);
-void launch_bucket_sort(hipStream_t s, const csv_sig *sig_raw, uint64_t n, int type_pos, int shift, const uint32_t *off, uint32_t *cur,
+// (the bucket counts come from the scan: ScanExtras::bucket_hist)
+void launch_bucket_sort(hipStream_t s, const csv_sig *sig_raw, uint64_t n, int type_pos, int shift, uint32_t *off /* the scan's bucket counts */, uint32_t *cur,
                         csv_sig *tmp, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out);
 void launch_sig_make_keys(hipStream_t s, const csv_sig *sig, uint64_t n, int len_bits, int type_bit_pos,
                           uint64_t *keys, uint32_t *vals);

@@ -57,14 +57,14 @@ static hipEvent_t get_event(csv_ctx *ctx)
     return e;
 }
 
-bool timer_begin(csv_ctx *ctx, int id)
+bool timer_begin(csv_ctx *ctx, int id, hipStream_t s)
 {
     if (!ctx->timing) return false;
     // every recorded event is a barrier packet in the queue (~5 us of idle device each): level 2 keeps them to the two groups a
     // roofline is quoted for
     if (ctx->timing == 2 && id != CSV_K_CIGAR_SCAN && id != CSV_K_DEPTH) return false;
-    Timer t; t.id = id; t.a = get_event(ctx); t.b = get_event(ctx);
-    (void)hipEventRecord(t.a, ctx->stream);
+    Timer t; t.id = id; t.a = get_event(ctx); t.b = get_event(ctx); t.s = s ? s : ctx->stream;
+    (void)hipEventRecord(t.a, t.s);
     ctx->timers.push_back(t);
     return true;
 }
@@ -72,7 +72,7 @@ bool timer_begin(csv_ctx *ctx, int id)
 void timer_end(csv_ctx *ctx)
 {
     if (!ctx->timing || ctx->timers.empty()) return;
-    (void)hipEventRecord(ctx->timers.back().b, ctx->stream);
+    (void)hipEventRecord(ctx->timers.back().b, ctx->timers.back().s);
 }
 
 static void fold_timers(csv_ctx *ctx)
@@ -99,6 +99,7 @@ struct DevReads {
 
 // device scalars + the ordering pass's bucket tables, zeroed together before every scan
 static constexpr size_t kCntBytes = 256 + 2 * (size_t)BK_N * 4;
+static constexpr uint64_t kMaxReadWords = 0x7ffff000ull;       // exclusive bound on one read's CIGAR words
 static inline uint32_t *bucket_off(ScanCounters *cnt) { return (uint32_t *)((char *)cnt + 256); }
 static inline uint32_t *bucket_cur(ScanCounters *cnt) { return bucket_off(cnt) + BK_N; }
 
@@ -139,20 +140,45 @@ static int stage_reads(csv_ctx *ctx, const csv_reads *r, DevReads &o)
     return CSV_OK;
 }
 
-static int check_reads(csv_ctx *ctx, const csv_reads *r)
+static int check_reads_ptrs(csv_ctx *ctx, const csv_reads *r)
 {
     if (!ctx) return CSV_EINVAL;
     if (!r || !r->cigar_off || (r->n_reads && (!r->pos || !r->flag || !r->mapq)) || (r->n_cigar && !r->cigar)) {
         ctx->err = "csv_reads: null array"; return CSV_EINVAL;
     }
     if (r->n_reads >= 0xffffffffull) { ctx->err = "csv_reads: more than 2^32-2 reads in one shard"; return CSV_EINVAL; }
-    // the kernels index the word array with these offsets: nothing reaches the device unless they are monotone and inside it
-    // (a read's own word count stays far below 2^31: the scan works in 32-bit read-relative indices)
+    return CSV_OK;
+}
+
+// Host arrays. The kernels index the word array with cigar_off: nothing reaches the device unless the offsets are monotone and
+// inside it (a read's own word count stays far below 2^31: the scan works in 32-bit read-relative indices).
+static int check_reads(csv_ctx *ctx, const csv_reads *r)
+{
+    int rc = check_reads_ptrs(ctx, r);
+    if (rc) return rc;
     for (uint64_t i = 0; i < r->n_reads; i++) {
         if (r->cigar_off[i + 1] < r->cigar_off[i]) { ctx->err = "csv_reads: cigar_off not monotone"; return CSV_EINVAL; }
-        if (r->cigar_off[i + 1] - r->cigar_off[i] >= 0x7ffff000ull) { ctx->err = "csv_reads: a read with 2^31 CIGAR words"; return CSV_EINVAL; }
+        if (r->cigar_off[i + 1] - r->cigar_off[i] >= kMaxReadWords) { ctx->err = "csv_reads: a read with 2^31 CIGAR words"; return CSV_EINVAL; }
     }
     if (r->cigar_off[r->n_reads] > r->n_cigar) { ctx->err = "csv_reads: cigar_off beyond n_cigar"; return CSV_EINVAL; }
+    return CSV_OK;
+}
+
+// The same test for arrays that already live in HBM (csvgpu_shard_wrap_dev): one small kernel, once per wrapped shard.
+static int check_reads_dev(csv_ctx *ctx, const csv_reads *r)
+{
+    int rc = check_reads_ptrs(ctx, r);
+    if (rc) return rc;
+    if ((rc = ensure_pinned(ctx, 4096))) return rc;
+    uint32_t *d_bad = nullptr;
+    CSV_HIP(ctx, hipMalloc((void **)&d_bad, 256));
+    hipError_t e = hipMemsetAsync(d_bad, 0, 4, ctx->stream);
+    if (e == hipSuccess) { launch_validate_offsets(ctx->stream, r->cigar_off, r->n_reads, r->n_cigar, kMaxReadWords, d_bad); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) { ctx->err = std::string("csv_reads: offset check failed: ") + hipGetErrorString(e); return CSV_EHIP; }
+    if (*(const uint32_t *)ctx->pinned) { ctx->err = "csv_reads: cigar_off not monotone or beyond n_cigar"; return CSV_EINVAL; }
     return CSV_OK;
 }
 
@@ -219,12 +245,15 @@ static KeyLayout key_layout(uint32_t depth_len, bool overflow, bool with_type)
     return k;
 }
 
-// After the scan and before the host reads the counters: bucket counts of the signatures, offsets, largest bucket.
-static void bucket_prepass(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t sig_cap, uint32_t depth_len, bool with_type, ScanCounters *cnt)
+// The ordering pass's bucket counts (and, for shards known to be coordinate-sorted, the depth tiles' candidate ranges) are taken
+// by the scan itself: nothing small runs between the scan and the depth pass.
+static ScanExtras scan_extras(ScanCounters *cnt, uint32_t depth_len, bool with_type, uint64_t *tile_range)
 {
-    TimerScope ts(ctx, CSV_K_SORT);
+    ScanExtras x;
     const KeyLayout k = key_layout(depth_len, false, with_type);
-    launch_bucket_hist(ctx->stream, sig_raw, cnt, sig_cap, k.type_pos, k.bucket_shift, bucket_off(cnt), bucket_cur(cnt));
+    x.bucket_hist = bucket_off(cnt); x.type_pos = k.type_pos; x.bucket_shift = k.bucket_shift;
+    x.tile_range = tile_range; x.n_tiles = tile_range ? depth_n_tiles(depth_len) : 0;
+    return x;
 }
 
 static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, uint32_t depth_len, uint32_t overflow, uint32_t max_bucket,
@@ -244,9 +273,10 @@ static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, u
     launch_sig_fix_ties_gather(ctx->stream, sig_raw, in_out ? w.k1 : w.k0, in_out ? w.v1 : w.v0, n, sig_sorted, start_out, end_out);
 }
 
-// depth chain on device arrays. pmax / ord scratch comes from `a`.
+// depth chain on device arrays. pmax / ord / range scratch comes from `a`; `ranges` != nullptr: the scan already produced the
+// tiles' candidate ranges (coordinate-sorted shard) and only the tile kernel remains.
 static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t *ref_end, const uint32_t *ckpt, bool unsorted, uint32_t depth_len,
-                       uint32_t *depth, ScanCounters *cnt)
+                       uint32_t *depth, ScanCounters *cnt, const uint64_t *ranges = nullptr)
 {
     const uint64_t n = d.n_reads;
     TimerScope ts(ctx, CSV_K_DEPTH);
@@ -254,9 +284,13 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
         if (depth && depth_len) CSV_HIP(ctx, hipMemsetAsync(depth, 0, (size_t)depth_len * 4, ctx->stream));
         return CSV_OK;
     }
+    if (ranges && !unsorted) {
+        launch_depth_tiles(ctx->stream, d, nullptr, ref_end, ckpt, depth_len, depth, cnt, ranges);
+        return CSV_OK;
+    }
     int32_t *pmax = (int32_t *)arena_alloc(a, n * 4);
     void *ptmp = arena_alloc(a, prefix_max_tmp_bytes(n));
-    void *ttmp = arena_alloc(a, depth_tiles_tmp_bytes(depth_len));
+    uint64_t *ttmp = (uint64_t *)arena_alloc(a, depth_tiles_tmp_bytes(depth_len));
     if (!pmax || !ptmp || !ttmp) { ctx->err = "arena exhausted (depth)"; return CSV_ENOMEM; }
     const uint32_t *ord = nullptr;
     const int32_t *pos_s = d.pos;
@@ -274,7 +308,8 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
         ord = perm; pos_s = (const int32_t *)pos_g; end_s = (const int32_t *)end_g;
     }
     launch_prefix_max(ctx->stream, end_s, pmax, n, ptmp);
-    launch_depth_tiles(ctx->stream, d, ord, pos_s, ref_end, pmax, ckpt, depth_len, depth, cnt, ttmp);
+    launch_depth_ranges(ctx->stream, pos_s, pmax, n, depth_len, ttmp);
+    launch_depth_tiles(ctx->stream, d, ord, ref_end, ckpt, depth_len, depth, cnt, ttmp);
     return CSV_OK;
 }
 static size_t depth_chain_bytes(uint64_t n, uint32_t depth_len = 0xffffffffu)
@@ -368,6 +403,7 @@ void csvgpu_destroy(csv_ctx *ctx)
     if (ctx->job_pin) (void)hipHostFree(ctx->job_pin);
     for (auto &b : ctx->host_pool) (void)hipHostFree(b.first);
     for (auto &b : ctx->host_live) (void)hipHostFree(b.first);       // blocks the caller never returned
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -417,9 +453,9 @@ int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, 
     if (!sig_raw) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
-        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, min_oplen, min_mapq, 1, sig_raw, cap, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, min_oplen, min_mapq, 1, sig_raw, cap, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt,
+                          scan_extras(dr.cnt, depth_len, false, nullptr));
     }
-    if (cap) bucket_prepass(ctx, sig_raw, cap, depth_len, false, dr.cnt);
     ScanCounters h;
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
     const uint64_t n = h.n_sig;
@@ -720,7 +756,9 @@ static csv_shard *shard_common(csv_ctx *ctx, csv_shard *sh)
     ok &= hipMalloc((void **)&sh->q_start, n * 4 + 16) == hipSuccess;
     ok &= hipMalloc((void **)&sh->q_end, n * 4 + 16) == hipSuccess;
     ok &= hipMalloc((void **)&sh->depth, (size_t)sh->depth_len * 4 + 16) == hipSuccess;
-    ok &= hipMalloc((void **)&sh->counters, kCntBytes) == hipSuccess;
+    sh->counters_bytes = align_up(kCntBytes, 256) + depth_tiles_tmp_bytes(sh->depth_len);
+    ok &= hipMalloc((void **)&sh->counters, sh->counters_bytes) == hipSuccess;
+    sh->tile_range = (uint64_t *)((char *)sh->counters + align_up(kCntBytes, 256));
     ok &= hipMalloc((void **)&sh->ckpt, ckpt_bytes(sh->d.n_cigar)) == hipSuccess;
     sh->sig_cap = std::max<uint64_t>(1u << 18, n * 2);
     ok &= hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)) == hipSuccess;
@@ -762,8 +800,9 @@ csv_shard *csvgpu_shard_upload(csv_ctx *ctx, const csv_reads *r, uint32_t depth_
 
 csv_shard *csvgpu_shard_wrap_dev(csv_ctx *ctx, const csv_reads *r, uint32_t depth_len)
 {
-    if (check_reads(ctx, r)) return nullptr;
+    if (!ctx) return nullptr;
     (void)hipSetDevice(ctx->device);
+    if (check_reads_dev(ctx, r)) return nullptr;
     csv_shard *sh = new (std::nothrow) csv_shard();
     if (!sh) { ctx->err = "out of host memory"; return nullptr; }
     sh->owned = false; sh->depth_len = depth_len; sh->d = *r;
@@ -878,7 +917,7 @@ csv_gate *csvgpu_gate_create(void) { return new (std::nothrow) csv_gate(); }
 void csvgpu_gate_destroy(csv_gate *gate)
 {
     if (!gate) return;
-    if (gate->last) (void)hipEventDestroy(gate->last);
+    if (gate->stream) { (void)hipSetDevice(gate->device); (void)hipStreamSynchronize(gate->stream); (void)hipStreamDestroy(gate->stream); }
     delete gate;
 }
 
@@ -926,7 +965,7 @@ void csvgpu_host_free(csv_ctx *ctx, void *p)
 struct csv_job {
     csv_shard *sh = nullptr;
     uint32_t min_oplen = 50; uint8_t min_mapq = 20; double min_pts_pct = 0.1;
-    hipEvent_t ev_mid = nullptr, ev_done = nullptr;
+    hipEvent_t ev_zero = nullptr, ev_scan = nullptr, ev_depth = nullptr, ev_mid = nullptr, ev_done = nullptr;
     char *pin = nullptr;                 // 512 B page-locked: [0,256) counters behind the scan, [256,512) counters at the end
     bool depth_queued = false, clustered = false, copied = false;
     uint64_t n = 0, n_del = 0, capacity = 0;
@@ -943,42 +982,70 @@ static char *job_pin_slot(csv_ctx *ctx)
     return p;
 }
 
-// scan + bucket counts (+ counters on their way to the host + depth pass, when the shard's sortedness is known)
+// scan (+ counters on their way to the host + depth pass, when the shard's sortedness is known). For a coordinate-sorted shard the
+// device sees scan -> depth tiles back to back: the scan leaves the bucket counts and the tiles' candidate ranges behind, the
+// counters travel beside the depth pass, and everything small (offsets, scatter, ranking, clustering) is queued behind it.
+// With a gate, the scan + depth pairs of all attached contexts go onto the gate's one stream — back to back in queue order, no
+// hand-over between queues — while each context's own (higher-priority) stream runs its small kernels beside the other lane's pair.
 static int job_queue_front(csv_ctx *ctx, csv_job *job)
 {
     csv_shard *sh = job->sh;
     hipStream_t s = ctx->stream;
     ScanCounters *cnt = (ScanCounters *)sh->counters;
     int rc;
-    CSV_HIP(ctx, hipMemsetAsync(cnt, 0, kCntBytes, s));
-    // with a gate: this context's scan starts behind the previous holder's depth pass, and hands the turn on behind its own
-    csv_gate *gate = sh->unsorted >= 0 ? ctx->gate : nullptr;
+    const bool sorted = sh->unsorted == 0;
+    CSV_HIP(ctx, hipMemsetAsync(cnt, 0, sorted ? sh->counters_bytes : kCntBytes, s));
+    csv_gate *gate = sorted ? ctx->gate : nullptr;
+    hipStream_t big = s;
     std::unique_lock<std::mutex> turn;
     if (gate) {
         turn = std::unique_lock<std::mutex>(gate->mu);
-        if (gate->last) CSV_HIP(ctx, hipStreamWaitEvent(s, gate->last, 0));
+        // (stream priorities — this stream low, the contexts' own high — measured 2 % slower: a small kernel waits for a whole
+        // workgroup slot of the resident big kernel either way)
+        if (!gate->stream) {
+            if (hipStreamCreateWithFlags(&gate->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); gate->stream = nullptr; }
+            gate->device = ctx->device;
+        }
+        if (gate->stream && gate->device == ctx->device) {
+            big = gate->stream;
+            CSV_HIP(ctx, hipEventRecord(job->ev_zero, s));                 // the pair starts behind this context's memset (and whatever it was queued behind)
+            CSV_HIP(ctx, hipStreamWaitEvent(big, job->ev_zero, 0));
+        }
     }
     {
-        TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
-        launch_cigar_scan(s, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                          sh->q_start, sh->q_end, sh->ckpt, cnt);
+        TimerScope ts(ctx, CSV_K_CIGAR_SCAN, big);
+        launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
+                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sorted ? sh->tile_range : nullptr));
     }
-    bucket_prepass(ctx, sh->sig_raw, sh->sig_cap, sh->depth_len, true, cnt);
     job->depth_queued = false;
     if (sh->unsorted >= 0) {
         // The depth pass does not depend on the signature count, so it is queued BEFORE the host waits for the counters: the
         // device works through it while the host wakes up, sizes the ordering and clustering launches and queues them.
-        CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, s));
-        CSV_HIP(ctx, hipEventRecord(job->ev_mid, s));
-        ctx->work.used = 0;
-        if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
-        launch_min_pts(s, cnt, job->min_pts_pct);
-        job->depth_queued = true;
-        if (gate) {
-            if (!gate->last) CSV_HIP(ctx, hipEventCreateWithFlags(&gate->last, hipEventDisableTiming));
-            CSV_HIP(ctx, hipEventRecord(gate->last, s));
-            turn.unlock();
+        // The counters leave on a stream that is idle at this point: the context's own when the pair runs on the gate's, else a side stream.
+        hipStream_t cs = s;
+        if (big == s) {
+            if (!ctx->side) CSV_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            cs = ctx->side;
         }
+        CSV_HIP(ctx, hipEventRecord(job->ev_scan, big));
+        CSV_HIP(ctx, hipStreamWaitEvent(cs, job->ev_scan, 0));
+        CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, cs));
+        CSV_HIP(ctx, hipEventRecord(job->ev_mid, cs));
+        if (big != s) {
+            TimerScope ts(ctx, CSV_K_DEPTH, big);
+            launch_depth_tiles(big, sh->d, nullptr, sh->ref_end, sh->ckpt, sh->depth_len, sh->depth, cnt, sh->tile_range);
+        } else {
+            ctx->work.used = 0;
+            if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt,
+                                  sorted ? sh->tile_range : nullptr))) return rc;
+        }
+        job->depth_queued = true;
+        if (big != s) {
+            CSV_HIP(ctx, hipEventRecord(job->ev_depth, big));
+            turn.unlock();
+            CSV_HIP(ctx, hipStreamWaitEvent(s, job->ev_depth, 0));             // min_pts and the clustering read what the depth pass leaves
+        }
+        launch_min_pts(s, cnt, job->min_pts_pct);
     }
     return CSV_OK;
 }
@@ -986,6 +1053,9 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
 static void job_free(csv_ctx *ctx, csv_job *job)
 {
     if (!job) return;
+    if (job->ev_zero) ctx->event_pool.push_back(job->ev_zero);
+    if (job->ev_scan) ctx->event_pool.push_back(job->ev_scan);
+    if (job->ev_depth) ctx->event_pool.push_back(job->ev_depth);
     if (job->ev_mid) ctx->event_pool.push_back(job->ev_mid);
     if (job->ev_done) ctx->event_pool.push_back(job->ev_done);
     delete job;
@@ -998,9 +1068,9 @@ csv_job *csvgpu_chr_job_begin(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, u
     csv_job *job = new (std::nothrow) csv_job();
     if (!job) { ctx->err = "out of host memory"; return nullptr; }
     job->sh = sh; job->min_oplen = min_oplen; job->min_mapq = min_mapq; job->min_pts_pct = min_pts_pct;
-    job->ev_mid = get_event(ctx); job->ev_done = get_event(ctx);
+    job->ev_zero = get_event(ctx); job->ev_scan = get_event(ctx); job->ev_depth = get_event(ctx); job->ev_mid = get_event(ctx); job->ev_done = get_event(ctx);
     job->pin = job_pin_slot(ctx);
-    if (!job->pin || !job->ev_mid || !job->ev_done) { ctx->err = "job: cannot allocate events / page-locked memory"; job_free(ctx, job); return nullptr; }
+    if (!job->pin || !job->ev_zero || !job->ev_scan || !job->ev_depth || !job->ev_mid || !job->ev_done) { ctx->err = "job: cannot allocate events / page-locked memory"; job_free(ctx, job); return nullptr; }
     if (arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads, sh->depth_len)) || job_queue_front(ctx, job)) { job_free(ctx, job); return nullptr; }
     return job;
 }

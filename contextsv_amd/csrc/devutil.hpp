@@ -103,6 +103,15 @@ __device__ __forceinline__ bool iv_neighbor(uint32_t s1, uint32_t e1, uint32_t s
     return (1.0 - mn) <= eps;
 }
 
+// bucket of a signature in the ordering pass's most-significant-digit split (sort.hip); counted by the scan's epilogue
+__device__ __forceinline__ uint32_t bk_bucket(const csv_sig &sg, int type_pos, int shift)
+{
+    uint64_t k = sg.start;
+    if (type_pos >= 0 && (sg.qpos_kind & 3u) != CSV_KIND_DEL) k |= 1ull << type_pos;
+    const uint64_t b = k >> shift;
+    return b < BK_N ? (uint32_t)b : BK_N - 1u;          // starts beyond the key width only occur with the overflow flag (fallback)
+}
+
 // A value every lane holds alike, moved to scalar registers: hipcc cannot prove that what comes out of LDS or of a load is
 // wave-uniform, and without the hint a loop nest driven by such values (scan.hip's read / chunk loops) is compiled as divergent control flow (exec-mask loops,
 // 64-bit VALU compares) — a third of that walk's VALU instructions.

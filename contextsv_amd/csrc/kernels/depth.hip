@@ -8,8 +8,9 @@
 // the ownership is turned around: one 1024-thread workgroup owns one 16 Ki-position tile of the
 // chromosome and keeps the tile's DIFFERENCE array in LDS (64 KiB + a 12 KiB work list -> 2
 // workgroups = 32 waves per CU). Per tile:
-//   1. candidate reads = one precomputed range (depth_ranges_kernel: reads are coordinate-sorted; a
-//      prefix maximum of the read ends bounds the range on the left);
+//   1. candidate reads = one precomputed range: for coordinate-sorted shards the CIGAR scan itself records, per tile, the
+//      first and last read that reach it (ScanExtras::tile_range), so nothing runs between the scan and this kernel;
+//      otherwise depth_ranges_kernel derives the ranges from a prefix maximum of the read ends;
 //   2. all threads together build an LDS work list: thread t loads candidate t's metadata, drops reads
 //      that end left of the tile or fail the depth filter, and binary-searches the read's checkpoints
 //      (scan.hip records the reference offset of a read at every 64-word CIGAR boundary) for the last
@@ -26,7 +27,6 @@
 
 namespace csv {
 
-constexpr int DEPTH_TILE = 16384;
 constexpr int DEPTH_THREADS = 1024;
 constexpr int DEPTH_WAVES = DEPTH_THREADS / WAVE;          // 8
 constexpr int DEPTH_PER_WAVE = DEPTH_TILE / DEPTH_WAVES;   // entries scanned per wave
@@ -171,14 +171,14 @@ __global__ __launch_bounds__(256) void depth_ranges_kernel(const int32_t *__rest
     const uint64_t T1 = min(T0 + (uint64_t)DEPTH_TILE, (uint64_t)depth_len);
     const uint64_t lo = wave_first_ge_i32(pmax_end, n_reads, (int64_t)T0, lane);
     const uint64_t hi = wave_first_ge_i32(pos_s, n_reads, (int64_t)T1 - 1, lane);
-    if (lane == 0) { tile_range[2 * (uint64_t)t] = lo; tile_range[2 * (uint64_t)t + 1] = hi; }
+    if (lane == 0) { tile_range[2 * (uint64_t)t] = ~lo; tile_range[2 * (uint64_t)t + 1] = hi; }      // encoding: common.hpp
 }
 
 __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int vec_ok, int dvec_ok,
     const uint32_t *__restrict__ ord,        // nullptr: reads already sorted by pos; else the tile ranges index `ord`
-    const int32_t *__restrict__ ref_end, const uint64_t *__restrict__ tile_range,
+    const int32_t *__restrict__ ref_end, const uint64_t *tile_range,        // (written by atomics of the previous kernel: no __restrict__ / read-only path)
     const uint32_t *__restrict__ ckpt,       // reference offset of the owning read at every CKPT_WORDS-word boundary (scan.hip)
     uint32_t depth_len, uint32_t *__restrict__ depth, ScanCounters *__restrict__ cnt)
 {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     for (int i = threadIdx.x; i < DEPTH_TILE + 4; i += DEPTH_THREADS) diff[i] = 0;
     // candidate range of this tile, precomputed for all tiles by depth_ranges_kernel (one load instead of two searches)
     if (threadIdx.x == 0) {
-        range_s[0] = tile_range[2 * (uint64_t)blockIdx.x]; range_s[1] = tile_range[2 * (uint64_t)blockIdx.x + 1];
+        range_s[0] = ~tile_range[2 * (uint64_t)blockIdx.x]; range_s[1] = tile_range[2 * (uint64_t)blockIdx.x + 1];
         blk_sum = 0; blk_nz = 0;
     }
     __syncthreads();
@@ -360,16 +360,20 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     }
 }
 
-size_t depth_tiles_tmp_bytes(uint32_t depth_len) { return align_up((((uint64_t)depth_len + DEPTH_TILE - 1) / DEPTH_TILE + 1) * 16, 256); }
+size_t depth_tiles_tmp_bytes(uint32_t depth_len) { return align_up(((size_t)depth_n_tiles(depth_len) + 1) * 16, 256); }
 
-void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *pos_s,
-                        const int32_t *ref_end, const int32_t *pmax_end, const uint32_t *ckpt, uint32_t depth_len,
-                        uint32_t *depth, ScanCounters *cnt, void *tmp)
+void launch_depth_ranges(hipStream_t s, const int32_t *pos_s, const int32_t *pmax_end, uint64_t n_reads, uint32_t depth_len, uint64_t *tile_range)
+{
+    const unsigned tiles = depth_n_tiles(depth_len);
+    if (!tiles) return;
+    hipLaunchKernelGGL(depth_ranges_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, pos_s, pmax_end, n_reads, depth_len, tiles, tile_range);
+}
+
+void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *ref_end, const uint32_t *ckpt,
+                        uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range)
 {
     if (depth_len == 0) return;
-    const unsigned tiles = (unsigned)(((uint64_t)depth_len + DEPTH_TILE - 1) / DEPTH_TILE);
-    uint64_t *tile_range = (uint64_t *)tmp;
-    hipLaunchKernelGGL(depth_ranges_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, pos_s, pmax_end, d.n_reads, depth_len, tiles, tile_range);
+    const unsigned tiles = depth_n_tiles(depth_len);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     const int dvec_ok = (((uintptr_t)depth) & 15u) == 0;
     hipLaunchKernelGGL(depth_tile_kernel, dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     const uint8_t *__restrict__ mapq, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
     int vec_ok, uint32_t depth_len, uint32_t start_limit, uint32_t min_oplen, uint32_t min_mapq, int emit,
     csv_sig *__restrict__ sig_out, uint64_t sig_cap, int32_t *__restrict__ ref_end, int32_t *__restrict__ q_start,
-    int32_t *__restrict__ q_end, uint32_t *__restrict__ ckpt, ScanCounters *__restrict__ cnt)
+    int32_t *__restrict__ q_end, uint32_t *__restrict__ ckpt, ScanCounters *__restrict__ cnt,
+    unsigned long long *__restrict__ tile_range, uint32_t n_tiles, uint32_t *__restrict__ bucket_hist, int hist_type_pos, int hist_shift)
 {
     __shared__ csv_sig buf[SIG_BUF];
     __shared__ uint32_t ring[SCAN_WAVES][RING_D][CHUNK_WORDS];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     if (threadIdx.x == 0) { buf_n = 0; blk_n_del = 0; blk_direct = 0; blk_overflow = 0; }
     // (the __syncthreads() after the split-point search below also publishes these)
 
-    uint32_t my_n_del = 0, my_overflow = 0;
+    uint32_t my_n_del = 0, my_overflow = 0, my_bucket_max = 0;
 
     // Work split: read lengths are log-normal, so handing out reads round-robin leaves the slowest wave with ~1.5x the
     // mean work (measured: waves alive 65 % of the kernel). Instead every wave takes the CONTIGUOUS run of reads whose
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
                                     if (lane == 0) g = atomicAdd(&cnt->n_sig, (unsigned long long)n_e);
                                     g = __shfl(g, 0, 64);
                                     if (e && g + rank < sig_cap) sig_out[g + rank] = sg;
+                                    if (e && bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
                                     if (lane == 0) atomicAdd(&blk_direct, 1u);
                                 }
                                 if (e) {
@@ -357,6 +359,20 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
             }
             acc_q += lane_q;
             ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)incl_ref, 63);
+        }
+
+        // Depth tiles this read reaches (ScanExtras::tile_range): the depth pass starts from these ranges, so no search kernel
+        // has to run between the two. Same filter as the depth pass (cnv_caller.cpp:491-495); positions as there, in uint32.
+        if (tile_range && ref_carry != 0 && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP))) {
+            const uint32_t first = p0 + 1u, last = first + ref_carry - 1u;
+            const uint32_t t0 = first >> DEPTH_TILE_SHIFT;
+            if (t0 < n_tiles && last >= first) {
+                const uint32_t t1 = min(last >> DEPTH_TILE_SHIFT, n_tiles - 1u);
+                for (uint32_t t = t0 + (uint32_t)lane; t <= t1; t += WAVE) {
+                    atomicMax(&tile_range[2 * (uint64_t)t], ~(unsigned long long)r);
+                    atomicMax(&tile_range[2 * (uint64_t)t + 1], (unsigned long long)r + 1ull);
+                }
+            }
         }
 
         const uint32_t q_total = wave_total_dpp(acc_q);
@@ -390,8 +406,16 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     }
     __syncthreads();
     const unsigned long long g = blk_gbase;
-    for (uint32_t i = threadIdx.x; i < nb; i += SCAN_THREADS)
-        if (g + i < sig_cap) sig_out[g + i] = buf[i];
+    for (uint32_t i = threadIdx.x; i < nb; i += SCAN_THREADS) {
+        const csv_sig sg = buf[i];
+        if (g + i < sig_cap) sig_out[g + i] = sg;
+        // the ordering pass's bucket counts, taken here so that no histogram kernel runs between the scan and the depth pass
+        if (bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
+    }
+    if (bucket_hist) {
+        my_bucket_max = wave_max(my_bucket_max);
+        if (lane == 0 && my_bucket_max) atomicMax(&cnt->max_len, my_bucket_max);
+    }
 }
 
 // Signature starts are < depth_len for coordinate-sorted input (start = pos + 1 <= contig length); the ordering pass sizes its
@@ -405,7 +429,7 @@ uint32_t scan_start_limit(uint32_t depth_len)
 
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
-                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt)
+                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &x)
 {
     if (d.n_reads == 0) return;
     // persistent-style grid: exactly as many workgroups as are resident at once (waves stride over the reads),
@@ -423,7 +447,24 @@ void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t dep
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     hipLaunchKernelGGL(cigar_scan_kernel, dim3(grid), dim3(SCAN_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
                        d.mapq, d.cigar_off, d.cigar, vec_ok, depth_len, scan_start_limit(depth_len), min_oplen, min_mapq, emit, sig_out, sig_cap,
-                       ref_end, q_start, q_end, ckpt, cnt);
+                       ref_end, q_start, q_end, ckpt, cnt, (unsigned long long *)x.tile_range, x.n_tiles, emit ? x.bucket_hist : nullptr, x.type_pos, x.bucket_shift);
+}
+
+// cigar_off of arrays that already live in HBM (csvgpu_shard_wrap_dev) gets the test the host arrays get in check_reads
+__global__ void validate_offsets_kernel(const uint64_t *__restrict__ cigar_off, uint64_t n_reads, uint64_t n_cigar, uint64_t max_words,
+                                        uint32_t *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_reads) return;
+    const uint64_t a = cigar_off[i];
+    bool wrong = a > n_cigar;
+    if (i < n_reads) { const uint64_t b = cigar_off[i + 1]; wrong |= b < a || b - a >= max_words; }
+    if (wrong) *bad = 1u;
+}
+
+void launch_validate_offsets(hipStream_t s, const uint64_t *cigar_off, uint64_t n_reads, uint64_t n_cigar, uint64_t max_words, uint32_t *bad)
+{
+    hipLaunchKernelGGL(validate_offsets_kernel, dim3((unsigned)((n_reads + 256) / 256)), dim3(256), 0, s, cigar_off, n_reads, n_cigar, max_words, bad);
 }
 
 }  // namespace csv

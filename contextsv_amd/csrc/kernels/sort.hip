@@ -239,43 +239,26 @@ int launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, u
 // A chromosome yields 1e4..1e6 signatures whose starts spread over the contig, so one most-significant-digit split into
 // BK_N buckets leaves a few dozen records per bucket; a wave then ranks its bucket with the full comparator
 // ((type, start) asc, end asc, (read, query offset) desc = the reference's lower_bound insertion order) and writes the final
-// records. Four launches instead of the fourteen of the LSD radix path (which stays as the fallback for skewed input: a
+// records. The bucket counts come with the scan (its epilogue counts what it emits); three launches — offsets, scatter, rank —
+// instead of the fourteen of the LSD radix path (which stays as the fallback for skewed input: a
 // bucket above BK_LOCAL_MAX, or starts that overflow the key).
-__device__ __forceinline__ uint32_t bk_bucket(const csv_sig &sg, int type_pos, int shift)
-{
-    uint64_t k = sg.start;
-    if (type_pos >= 0 && (sg.qpos_kind & 3u) != CSV_KIND_DEL) k |= 1ull << type_pos;
-    const uint64_t b = k >> shift;
-    return b < BK_N ? (uint32_t)b : BK_N - 1u;          // starts beyond the key width only occur with the overflow flag (fallback)
-}
-
-__global__ void bk_hist_kernel(const csv_sig *__restrict__ sig, const ScanCounters *__restrict__ cnt, uint64_t cap, int type_pos, int shift,
-                               uint32_t *__restrict__ hist)
-{
-    const uint64_t n = cnt->n_sig < cap ? cnt->n_sig : cap;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        atomicAdd(&hist[bk_bucket(sig[i], type_pos, shift)], 1u);
-}
-
-// one workgroup: counts -> exclusive offsets (hist in place) + scatter cursors, largest bucket -> cnt->max_len
-__global__ void __launch_bounds__(1024) bk_prep_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ cur, ScanCounters *__restrict__ cnt)
+// one workgroup: the scan's bucket counts -> exclusive offsets (in place) + scatter cursors
+__global__ void __launch_bounds__(1024) bk_prep_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ cur)
 {
     constexpr int PER = BK_N / 1024;
-    __shared__ uint32_t wsum[16], wmax[16];
-    uint32_t v[PER], tot = 0, mx = 0;
+    __shared__ uint32_t wsum[16];
+    uint32_t v[PER], tot = 0;
 #pragma unroll
-    for (int k = 0; k < PER; k++) { v[k] = hist[threadIdx.x * PER + k]; tot += v[k]; mx = max(mx, v[k]); }
+    for (int k = 0; k < PER; k++) { v[k] = hist[threadIdx.x * PER + k]; tot += v[k]; }
     const uint32_t incl = wave_incl_sum_dpp(tot);
-    mx = wave_max(mx);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 63) { wsum[w] = incl; wmax[w] = mx; }
+    if (l == 63) wsum[w] = incl;
     __syncthreads();
-    uint32_t base = 0, gmax = 0;
-    for (int k = 0; k < 16; k++) { if (k < w) base += wsum[k]; gmax = max(gmax, wmax[k]); }
+    uint32_t base = 0;
+    for (int k = 0; k < w; k++) base += wsum[k];
     uint32_t run = base + incl - tot;
 #pragma unroll
     for (int k = 0; k < PER; k++) { hist[threadIdx.x * PER + k] = run; cur[threadIdx.x * PER + k] = run; run += v[k]; }
-    if (threadIdx.x == 0) cnt->max_len = gmax;
 }
 
 __global__ void bk_scatter_kernel(const csv_sig *__restrict__ sig, uint64_t n, int type_pos, int shift, uint32_t *__restrict__ cur,
@@ -337,16 +320,11 @@ __global__ void __launch_bounds__(256) bk_local_kernel(const csv_sig *__restrict
     }
 }
 
-void launch_bucket_hist(hipStream_t s, const csv_sig *sig, ScanCounters *cnt, uint64_t cap, int type_pos, int shift, uint32_t *hist, uint32_t *cur)
-{
-    hipLaunchKernelGGL(bk_hist_kernel, dim3(256), dim3(256), 0, s, sig, cnt, cap, type_pos, shift, hist);
-    hipLaunchKernelGGL(bk_prep_kernel, dim3(1), dim3(1024), 0, s, hist, cur, cnt);
-}
-
-void launch_bucket_sort(hipStream_t s, const csv_sig *sig_raw, uint64_t n, int type_pos, int shift, const uint32_t *off, uint32_t *cur,
+void launch_bucket_sort(hipStream_t s, const csv_sig *sig_raw, uint64_t n, int type_pos, int shift, uint32_t *off, uint32_t *cur,
                         csv_sig *tmp, csv_sig *sig_sorted, uint32_t *start_out, uint32_t *end_out)
 {
     if (!n) return;
+    hipLaunchKernelGGL(bk_prep_kernel, dim3(1), dim3(1024), 0, s, off, cur);
     hipLaunchKernelGGL(bk_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sig_raw, n, type_pos, shift, cur, tmp);
     hipLaunchKernelGGL(bk_local_kernel, dim3(BK_N / 4), dim3(256), 0, s, tmp, off, n, type_pos, sig_sorted, start_out, end_out);
 }

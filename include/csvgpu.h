@@ -250,11 +250,13 @@ csv_job *csvgpu_chr_job_begin(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen
 int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity);
 int csvgpu_chr_job_end(csv_ctx *ctx, csv_job *job, csv_chr_result *result);
 
-/* Several contexts on one GPU (one per host thread, each with its own stream) keep several chromosomes in flight. A gate makes
- * their bandwidth-bound phases (CIGAR scan + depth pass) take turns on the device — ordered with events, no host blocking — while
- * the latency-bound tail of one chromosome (ordering, clustering, copies, host wake-ups) overlaps the scan of the next. The
- * reference gets its overlap from a thread pool over chromosomes (sv_caller.cpp:827-863); this is the device-side counterpart.
- * Attach the same gate to every context of the GPU before running pipelines concurrently; detach with gate == NULL. */
+/* Several chromosomes in flight on one GPU: several contexts (one per host thread, each with its own stream) that share a gate.
+ * They queue the scan + depth pair of their jobs onto the gate's ONE stream — so the bandwidth-bound kernels of all lanes run back
+ * to back in queue order, with no hand-over between queues — while each context's own stream carries that lane's small kernels
+ * (ordering, clustering, copies), which then run beside another lane's pair, and the host merge of one chromosome hides behind
+ * the device work of the others. The reference gets its overlap from a thread pool over chromosomes (sv_caller.cpp:827-863);
+ * this is the device-side counterpart. Attach the same gate to every context of ONE GPU before running pipelines concurrently;
+ * detach with gate == NULL. Jobs on shards that are not coordinate-sorted ignore the gate. */
 typedef struct csv_gate csv_gate;
 csv_gate *csvgpu_gate_create(void);
 void csvgpu_gate_destroy(csv_gate *gate);                 /* after every attached context is destroyed or detached */

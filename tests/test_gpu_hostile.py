@@ -101,3 +101,24 @@ def test_window_and_viterbi_on_extreme_values(ctx, oracle):
         ost, oll = oracle.viterbi(hmm, o1, o2, pf, np.asarray(off, np.uint64))
         assert np.array_equal(st, ost)
         np.testing.assert_allclose(ll, oll, rtol=0, atol=1e-6, equal_nan=True)
+
+
+def test_offsets_that_leave_the_word_array_are_refused(ctx):
+    """The kernels index the CIGAR words with cigar_off: a table that is not monotone, or that points past the array, must be
+    turned away on the host (CSV_EINVAL) — never reach the device."""
+    from contextsv_amd import CsvError
+    reads = _hostile(11, 50, 3000)
+    for breakage in ("swap", "dip", "beyond"):
+        off = reads.cigar_off.copy()
+        if breakage == "swap":
+            k = int(np.argmax(np.diff(off.astype(np.int64)) > 0))
+            off[k], off[k + 1] = off[k + 1], off[k]
+        elif breakage == "dip":
+            off[1:-1] += np.uint64(1 << 20)       # the last entry now lies below its predecessor
+        else:
+            off[1:] += np.uint64(1 << 20)         # monotone, but past the end of the word array
+        bad = Reads(reads.pos, reads.flag, reads.mapq, reads.cigar_off, reads.cigar)
+        bad.cigar_off = off                       # bypass the wrapper's own length check: this is the C-ABI's test
+        for call in (lambda: ctx.cigar_scan(bad, 3000), lambda: ctx.aln_intervals(bad), lambda: ctx.depth(bad, 3000), lambda: ctx.upload(bad, 3000)):
+            with pytest.raises(CsvError):
+                call()
