@@ -53,7 +53,8 @@ typedef struct csv_reads {
     const uint16_t *flag;       /* [n_reads] BAM FLAG */
     const uint8_t  *mapq;       /* [n_reads] MAPQ */
     const int32_t  *tid;        /* [n_reads] reference id (carried, not interpreted by kernels; may be NULL) */
-    const uint64_t *cigar_off;  /* [n_reads+1] first CIGAR word of each read */
+    const uint64_t *cigar_off;  /* [n_reads+1] first CIGAR word of each read; non-decreasing, cigar_off[n_reads] <= n_cigar, < 2^31 words
+                                 * per read — entry points return CSV_EINVAL otherwise (nothing reaches the device) */
     const uint32_t *cigar;      /* [n_cigar] packed CIGAR words */
 } csv_reads;
 
