@@ -52,6 +52,7 @@ def main():
                     "to back on the gate's stream, their small kernels beside them); the big kernels stretch by ~10 %% under the co-running "
                     "small ones, the throughput gains ~25 %% over one lane; four lanes are slower again")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timers around every kernel group, not only scan and depth")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="no HIP events around the kernels (what the timers themselves cost; the roofline block is then empty)")
     ap.add_argument("--no-two-lanes", action="store_true", help="skip the extra measurement with the other lane count (1 <-> 2)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0, help="fraction of the shard's reads given to the CPU baseline")
     args = ap.parse_args()
@@ -142,7 +143,7 @@ def main():
     if args.warmup:
         job(args.warmup)
     for c in lane_ctx:
-        c.timing_enable(1 if args.time_all_kernels else 2)       # 2: events only around the two bandwidth-bound groups (each event idles the queue ~5 us)
+        c.timing_enable(0 if args.no_kernel_timers else (1 if args.time_all_kernels else 2))       # 2: events only around the two bandwidth-bound groups (each event idles the queue ~5 us)
         c.timing_reset()
     barrier()
     t0 = time.perf_counter()

@@ -197,6 +197,30 @@ class Context:
             raise CsvError(_lib.CSV_ENOMEM, (self.lib.csvgpu_last_error(self.h) or b"").decode())
         return Shard(self, h, reads.n_reads, depth_len)
 
+    def wrap_device_ptrs(self, n_reads: int, n_cigar: int, pos: int, flag: int, mapq: int, cigar_off: int, cigar: int, depth_len: int, keep=None) -> "Shard":
+        """Arrays that already live in HBM, given as device addresses (csv_reads layouts), wrapped without a copy
+        (csvgpu_shard_wrap_dev). They must outlive the shard; `keep` is held by it for that purpose."""
+        r = csv_reads()
+        r.n_reads, r.n_cigar = n_reads, n_cigar
+        r.pos, r.flag, r.mapq, r.tid, r.cigar_off, r.cigar = pos, flag, mapq, None, cigar_off, cigar       # (void * fields)
+        h = self.lib.csvgpu_shard_wrap_dev(self.h, C.byref(r), depth_len)
+        if not h:
+            raise CsvError(_lib.CSV_EINVAL, (self.lib.csvgpu_last_error(self.h) or b"").decode())
+        sh = Shard(self, h, n_reads, depth_len)
+        sh._keep = keep
+        return sh
+
+    def wrap_device(self, pos, flag, mapq, cigar_off, cigar, depth_len: int) -> "Shard":
+        """The same for torch tensors on this context's device (int32 / int16 / uint8 / int64 / int32 bit patterns of csv_reads)."""
+        n, m = int(pos.numel()), int(cigar.numel())
+        if not (flag.numel() == n and mapq.numel() == n and cigar_off.numel() == n + 1):
+            raise ValueError("wrap_device: array lengths disagree")
+        for t, size in ((pos, 4), (flag, 2), (mapq, 1), (cigar_off, 8), (cigar, 4)):
+            if not t.is_cuda or not t.is_contiguous() or t.element_size() != size:
+                raise ValueError("wrap_device: tensors must be contiguous device tensors of the csv_reads element sizes")
+        return self.wrap_device_ptrs(n, m, pos.data_ptr(), flag.data_ptr(), mapq.data_ptr(), cigar_off.data_ptr(), cigar.data_ptr(), depth_len,
+                                     keep=(pos, flag, mapq, cigar_off, cigar))
+
 
 @dataclass
 class ChrResult:

@@ -28,6 +28,7 @@ struct Timer {
     hipEvent_t a, b;
     int id;
     hipStream_t s;
+    bool own_a = true, own_b = true;   // returned to the event pool when the timer is folded (an event may close one group and open the next)
 };
 
 struct Arena {                     // grow-only bump allocator over one device buffer; reset per entry point

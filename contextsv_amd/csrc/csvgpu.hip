@@ -82,7 +82,8 @@ static void fold_timers(csv_ctx *ctx)
         if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
             ctx->t_ms[t.id] += ms; ctx->t_n[t.id]++;
         }
-        ctx->event_pool.push_back(t.a); ctx->event_pool.push_back(t.b);
+        if (t.own_a) ctx->event_pool.push_back(t.a);
+        if (t.own_b) ctx->event_pool.push_back(t.b);
     }
     ctx->timers.clear();
 }
@@ -994,6 +995,9 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
     ScanCounters *cnt = (ScanCounters *)sh->counters;
     int rc;
     const bool sorted = sh->unsorted == 0;
+    if (!job->ev_scan) job->ev_scan = get_event(ctx);          // (handed to the timers by an earlier pass of this job)
+    if (!job->ev_depth) job->ev_depth = get_event(ctx);
+    if (!job->ev_scan || !job->ev_depth) { ctx->err = "job: cannot allocate events"; return CSV_ENOMEM; }
     CSV_HIP(ctx, hipMemsetAsync(cnt, 0, sorted ? sh->counters_bytes : kCntBytes, s));
     csv_gate *gate = sorted ? ctx->gate : nullptr;
     hipStream_t big = s;
@@ -1012,7 +1016,16 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
             CSV_HIP(ctx, hipStreamWaitEvent(big, job->ev_zero, 0));
         }
     }
-    {
+    // On the gate's stream every recorded event is a barrier packet between the big kernels of ALL lanes (~5 us each): the pair is
+    // timed with the two events the job records there anyway plus one in front (scan = ev_scan - t0, depth = ev_depth - ev_scan).
+    const bool pair_timers = big != s && ctx->timing != 0;
+    hipEvent_t t0 = nullptr;
+    if (pair_timers) {
+        t0 = get_event(ctx);
+        if (t0) CSV_HIP(ctx, hipEventRecord(t0, big));
+        launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
+                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range));
+    } else {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN, big);
         launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
                           sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sorted ? sh->tile_range : nullptr));
@@ -1031,7 +1044,9 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
         CSV_HIP(ctx, hipStreamWaitEvent(cs, job->ev_scan, 0));
         CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, cs));
         CSV_HIP(ctx, hipEventRecord(job->ev_mid, cs));
-        if (big != s) {
+        if (pair_timers) {
+            launch_depth_tiles(big, sh->d, nullptr, sh->ref_end, sh->ckpt, sh->depth_len, sh->depth, cnt, sh->tile_range);
+        } else if (big != s) {
             TimerScope ts(ctx, CSV_K_DEPTH, big);
             launch_depth_tiles(big, sh->d, nullptr, sh->ref_end, sh->ckpt, sh->depth_len, sh->depth, cnt, sh->tile_range);
         } else {
@@ -1041,9 +1056,16 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
         }
         job->depth_queued = true;
         if (big != s) {
-            CSV_HIP(ctx, hipEventRecord(job->ev_depth, big));
+            hipEvent_t depth_done = job->ev_depth;
+            CSV_HIP(ctx, hipEventRecord(depth_done, big));
             turn.unlock();
-            CSV_HIP(ctx, hipStreamWaitEvent(s, job->ev_depth, 0));             // min_pts and the clustering read what the depth pass leaves
+            if (pair_timers && t0) {                 // the timers now own the three events (folded when the times are read)
+                Timer a; a.id = CSV_K_CIGAR_SCAN; a.a = t0; a.b = job->ev_scan; a.s = big;
+                Timer b; b.id = CSV_K_DEPTH; b.a = job->ev_scan; b.b = job->ev_depth; b.s = big; b.own_a = false;
+                ctx->timers.push_back(a); ctx->timers.push_back(b);
+                job->ev_scan = nullptr; job->ev_depth = nullptr;
+            }
+            CSV_HIP(ctx, hipStreamWaitEvent(s, depth_done, 0));                // min_pts and the clustering read what the depth pass leaves
         }
         launch_min_pts(s, cnt, job->min_pts_pct);
     }

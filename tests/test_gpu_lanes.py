@@ -24,6 +24,8 @@ def test_lanes_give_the_single_context_result(ctx):
             sh.free()
         ctx.set_gate(gate); ctx2.set_gate(gate)
         shards = [ctx.upload(syn_a.reads, syn_a.depth_len), ctx2.upload(syn_b.reads, syn_b.depth_len)]
+        for c in (ctx, ctx2):                            # as bench.py runs: HIP-event timers around the scan + depth pair on the gate's stream
+            c.timing_enable(2); c.timing_reset()
         for steps in ([3, 3], [5, 2]):
             for lane in (0, 1):                          # the hook returns lane 0's last result: run with each contig in lane 0
                 order = [lane, 1 - lane]
@@ -33,7 +35,12 @@ def test_lanes_give_the_single_context_result(ctx):
                 assert st.n_signatures == n_sig and st.depth_sum == depth_sum
                 assert got.tobytes() == exp.tobytes() and len(got) > 10
                 assert total == steps[0] * len(want[0][0]) + steps[1] * len(want[1][0])
+        for c, n_steps in ((ctx, 2 * (3 + 5)), (ctx2, 2 * (3 + 2))):
+            t = c.timing()
+            assert t["cigar_scan"][1] == n_steps and t["depth"][1] == n_steps and t["cigar_scan"][0] > 0 and t["depth"][0] > 0
     finally:
+        for c in (ctx, ctx2):
+            c.timing_enable(0)
         ctx.set_gate(None)
         for sh in shards:
             sh.free()
@@ -80,4 +87,54 @@ def test_job_calls_out_of_order(ctx):
         assert (ref.n_sig, ref.depth_sum, ref.min_pts) == (res.n_sig, res.depth_sum, res.min_pts)
     finally:
         sh.free()
+        syn.free()
+
+
+def test_wrapped_device_arrays_run_the_same_pipeline_and_bad_offsets_are_refused(ctx):
+    """csvgpu_shard_wrap_dev: arrays already in HBM, no copy. Same pipeline results as the uploaded shard (the first job on a wrapped
+    shard does not know yet whether it is coordinate-sorted: the other branch of the job), and the offsets are validated by a
+    kernel — a table that leaves the word array never reaches the scan."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")                         # the runtime the library itself is linked against
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    held = []
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), max(a.nbytes, 16)) == 0
+        held.append(p)
+        assert hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0          # hipMemcpyHostToDevice
+        return p.value
+
+    syn = host.SynthShard(seed=21, chr_len=2_000_000, depth=15.0, tech=0, threads=4)
+    r = syn.reads
+    up = ctx.upload(r, syn.depth_len)
+    wr = None
+    try:
+        want = up.pipeline(); w = up.fetch(want, want_depth=True)
+        d_pos, d_flag, d_mapq, d_off, d_cig = (to_device(a) for a in (r.pos, r.flag, r.mapq, r.cigar_off, r.cigar))
+        wr = ctx.wrap_device_ptrs(r.n_reads, r.n_cigar, d_pos, d_flag, d_mapq, d_off, d_cig, syn.depth_len)
+        for _ in range(2):                                 # second pass: sortedness known, depth pass queued behind the scan
+            got = wr.pipeline(); g = wr.fetch(got, want_depth=True)
+            assert (got.n_sig, got.n_del, got.depth_sum, got.depth_nonzero, got.min_pts) == (want.n_sig, want.n_del, want.depth_sum, want.depth_nonzero, want.min_pts)
+            for k in w:
+                assert np.array_equal(w[k], g[k]), k
+        for breakage in ("dip", "beyond"):
+            off = r.cigar_off.copy()
+            if breakage == "dip":
+                off[5] = off[7] + np.uint64(1)
+            else:
+                off[1:] += np.uint64(1 << 20)
+            with pytest.raises(cs.CsvError):
+                ctx.wrap_device_ptrs(r.n_reads, r.n_cigar, d_pos, d_flag, d_mapq, to_device(off), d_cig, syn.depth_len)
+    finally:
+        if wr is not None:
+            wr.free()
+        up.free()
+        ctx.synchronize()
+        for p in held:
+            hip.hipFree(p)
         syn.free()
