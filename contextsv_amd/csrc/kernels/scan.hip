@@ -99,24 +99,6 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t i)
 {
     return ((uint64_t)bcast32((uint32_t)(v >> 32), i) << 32) | bcast32((uint32_t)v, i);
 }
-struct ScanMd {
-    uint64_t c0, c1;
-    uint32_t p0, fl, mq, unsorted;
-};
-__device__ __forceinline__ ScanMd scan_load_md(uint64_t r, uint64_t n_reads, const int32_t *__restrict__ pos,
-                                               const uint16_t *__restrict__ flag, const uint8_t *__restrict__ mapq,
-                                               const uint64_t *__restrict__ cigar_off)
-{
-    ScanMd m; m.c0 = 0; m.c1 = 0; m.p0 = 0; m.fl = 0; m.mq = 0; m.unsorted = 0;
-    if (r < n_reads) {
-        m.c0 = cigar_off[r]; m.c1 = cigar_off[r + 1];
-        const int32_t p = pos[r];
-        m.p0 = (uint32_t)p; m.fl = flag[r]; m.mq = mapq[r];
-        m.unsorted = (r > 0 && p < pos[r - 1]) ? 1u : 0u;
-    }
-    return m;
-}
-
 // 54 VGPRs; the LDS (ring + signature buffer) sets the occupancy
 __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
@@ -128,12 +110,12 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
 {
     __shared__ csv_sig buf[SIG_BUF];
     __shared__ uint32_t ring[SCAN_WAVES][RING_D][CHUNK_WORDS];
-    __shared__ uint32_t buf_n, blk_n_del, blk_direct, blk_overflow;
+    __shared__ uint32_t buf_n, blk_n_del, blk_overflow;
     __shared__ unsigned long long blk_gbase;
 
     const int lane = lane_id();
     const int wave = (int)uniform32(threadIdx.x >> 6);
-    if (threadIdx.x == 0) { buf_n = 0; blk_n_del = 0; blk_direct = 0; blk_overflow = 0; }
+    if (threadIdx.x == 0) { buf_n = 0; blk_n_del = 0; blk_overflow = 0; }
     // (the __syncthreads() after the split-point search below also publishes these)
 
     uint32_t my_n_del = 0, my_overflow = 0, my_bucket_max = 0;
@@ -343,7 +325,6 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
                                     g = __shfl(g, 0, 64);
                                     if (e && g + rank < sig_cap) sig_out[g + rank] = sg;
                                     if (e && bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
-                                    if (lane == 0) atomicAdd(&blk_direct, 1u);
                                 }
                                 if (e) {
                                     my_n_del += (kind == CSV_KIND_DEL);
