@@ -66,6 +66,45 @@ def test_seams_on_hostile_shards(ctx, oracle, seed, n_reads, depth_len, sorted_p
         sh.free()
 
 
+def test_reads_that_span_hundreds_of_depth_tiles(ctx, oracle):
+    """The scan records, per 16 Ki-position depth tile, the first and last read that reaches it, 64 tiles per wave step: reads with
+    megabase reference skips and deletions (more than 64 tiles each), reads running off the contig's end, a read covering the whole
+    contig, short reads in between — depth map, sums and the pipeline's calls against the oracle."""
+    depth_len = 5_000_000
+    rng = np.random.default_rng(5)
+    pos, cig = [], []
+    for r in range(300):
+        p = int(rng.integers(0, depth_len - 2000))
+        ops = [(M, int(rng.integers(30, 400)))]
+        kind = r % 6
+        if kind == 0:
+            ops += [(N, int(rng.integers(1_100_000, 3_000_000))), (M, 500), (D, 70), (M, 300)]          # > 64 tiles
+        elif kind == 1:
+            ops += [(D, int(rng.integers(200_000, 1_500_000))), (M, 200), (I, 60), (M, 100)]
+        elif kind == 2:
+            p = depth_len - int(rng.integers(1, 3000)); ops += [(D, 90), (M, 5000)]                       # hangs over the end
+        else:
+            ops += [(I, 55), (M, 800), (D, 51), (M, 900), (S, 120)]
+        pos.append(p); cig.append(ops)
+    pos.append(0); cig.append([(M, 10), (N, depth_len - 100), (M, 500)])                                  # covers every tile
+    order = np.argsort(np.asarray(pos), kind="stable")
+    reads = Reads.from_cigar_lists(np.asarray(pos)[order], np.zeros(len(pos), np.uint16), np.full(len(pos), 60, np.uint8), [cig[i] for i in order])
+    od, os_, onz = oracle.depth(reads, depth_len)
+    d, s, nz = ctx.depth(reads, depth_len)
+    assert np.array_equal(d, od) and (s, nz) == (os_, onz)
+    sh = ctx.upload(reads, depth_len)
+    try:
+        for _ in range(2):
+            res = sh.pipeline(eps=0.1, min_pts_pct=0.1)
+            out = sh.fetch(res, want_depth=True)
+            assert np.array_equal(out["depth"], od) and (res.depth_sum, res.depth_nonzero) == (os_, onz)
+            sig = oracle.cigar_scan(reads, depth_len)
+            kind = sig["qpos_kind"] & 3
+            _same_sigs(out["sig_del"], sig[kind == 1]); _same_sigs(out["sig_ins"], sig[kind != 1])
+    finally:
+        sh.free()
+
+
 def test_window_and_viterbi_on_extreme_values(ctx, oracle):
     """Depth maps of zeros / 2^32-1, windows past the map, one-position regions, mean coverage 1e-300; observations of +-1e300,
     BAF and population frequencies exactly 0 and 1: the kernels give the oracle's numbers (NaN and inf included)."""
