@@ -62,7 +62,7 @@ class Reads:
 
 
 class Gate:
-    """csv_gate: several Contexts on one GPU take turns with their bandwidth-bound phases (csvgpu_gate_*)."""
+    """csv_gate: several Contexts on one GPU queue their scan + depth pairs back to back on the gate's one stream (csvgpu_gate_*)."""
 
     def __init__(self):
         self.lib = _lib.load()

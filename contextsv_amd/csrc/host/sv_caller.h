@@ -97,7 +97,7 @@ public:
                                              std::vector<ChrStats> &stats);
 
     // Several chromosomes in flight on one GPU: every lane is a context of its own (own stream; attach one csv_gate to all of them so
-    // that their scan + depth phases take turns) and runs processResidentChromosomesPipelined on its shards in its own pair of threads.
+    // that their scan + depth pairs run back to back on the gate's stream) and runs processResidentChromosomesPipelined on its shards in its own pair of threads.
     struct Lane { csv_ctx *ctx; std::vector<csv_shard *> shards; };
     static void processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double dbscan_epsilon, double dbscan_min_pts_pct,
                                      std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats);
