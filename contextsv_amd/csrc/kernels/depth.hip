@@ -16,7 +16,7 @@
 //      (scan.hip records the reference offset of a read at every 64-word CIGAR boundary) for the last
 //      boundary left of the tile;
 //   3. waves pull items from an LDS counter and walk 1 KiB CIGAR chunks from that boundary (16-byte loads,
-//      one DPP wave scan per chunk, next chunk in flight), applying +1/-1 with LDS atomics, until the
+//      one DPP wave scan per chunk, four chunks in flight), applying +1/-1 with LDS atomics, until the
 //      tile's right edge;
 //   4. the tile is scanned in LDS and depth is written once, coalesced, 16 B per lane, while sum and
 //      non-zero count are reduced.
@@ -32,6 +32,7 @@ constexpr int DEPTH_WAVES = DEPTH_THREADS / WAVE;          // 8
 constexpr int DEPTH_PER_WAVE = DEPTH_TILE / DEPTH_WAVES;   // entries scanned per wave
 constexpr int DEPTH_ROUNDS = DEPTH_PER_WAVE / (4 * WAVE);  // rounds of 256 entries
 constexpr int WL_CAP = 512;                                // work-list items staged per batch (12 KiB of LDS)
+constexpr int DEPTH_PF = 3;                                // a walk keeps DEPTH_PF + 1 chunks in flight ahead of the one being worked on (1 -> 4: -4 %)
 
 // ------------------------------------------------------------------------------- prefix max
 constexpr int PM_THREADS = 256;
@@ -260,49 +261,67 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
             // Positions are kept relative to the tile's left edge in 32-bit signed arithmetic (coordinates and run lengths are
             // below 2^31, the BAM limit): a run [rel, rel + len) clips to [max(rel,0), min(rel+len, TW)) with one max and one min,
             // and a run with no aligned bases (len masked to 0) clips to nothing, so no separate op test is needed.
-            int32_t base_rel = (int32_t)uniform32(wl_p1[it] + wl_carry[it] - (uint32_t)T0);  // wave-uniform: first staged word of the chunk
-            uint32_t w[4], w1[4] = {0, 0, 0, 0};
-            const bool whole0 = vec_ok && chunk0 + 4 * WAVE <= n_cigar;
-            if (whole0) { const uint4 v = *reinterpret_cast<const uint4 *>(cigar + chunk0 + (uint64_t)lane * 4); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-            else depth_load4(cigar, n_cigar, vec_ok, chunk0 + (uint64_t)lane * 4, w);
-            for (uint32_t o0 = 0; o0 < nrem; o0 += 4 * WAVE) {                      // o0: word offset of this chunk from chunk0
-                if (base_rel >= TW) break;                                          // rest of the read lies right of the tile
-                const bool more = o0 + 4 * WAVE < nrem;
-                if (more) {                                                         // next 1 KiB in flight
-                    const uint64_t nx = chunk0 + o0 + 4 * WAVE;
-                    if (vec_ok && nx + 4 * WAVE <= n_cigar) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(cigar + nx + (uint64_t)lane * 4); w1[0] = v.x; w1[1] = v.y; w1[2] = v.z; w1[3] = v.w;
-                    } else depth_load4(cigar, n_cigar, vec_ok, nx + (uint64_t)lane * 4, w1);
-                }
-                // only the first and the last chunk of an item can hold words of a neighbouring read
-                if (!((int32_t)o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
-                    const int32_t o = (int32_t)o0 + lane * 4;
+            int32_t base_rel = (int32_t)uniform32(wl_p1[it] + wl_carry[it] - (uint32_t)T0);  // wave-uniform: position of the chunk's first staged word, relative to the tile
+            // The walk is bound by the bytes its 32 waves per CU keep in flight more than by anything else: several chunks are
+            // requested ahead of the one being worked on. (Stopping the prefetch exactly at the tile's right edge — the checkpoints
+            // tell where, one 64-lane look-up per item — removes the quarter of the HBM traffic that lies beyond it and costs more
+            // than it saves: the kernel does not wait for bandwidth.)
+            auto load_chunk = [&](uint32_t off, uint32_t (&dst)[4]) {
+                const uint64_t c = chunk0 + off;
+                if (vec_ok && c + 4 * WAVE <= n_cigar) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(cigar + c + (uint64_t)lane * 4); dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                } else depth_load4(cigar, n_cigar, vec_ok, c + (uint64_t)lane * 4, dst);
+            };
+            {
+                const uint32_t n_chunks = (nrem + 4 * WAVE - 1) / (4 * WAVE);
+                uint32_t w[DEPTH_PF + 1][4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (!((o + k >= c0rel) && ((uint32_t)(o + k) < nrem))) w[k] = (uint32_t)OP_P;
-                }
-                uint32_t rl[4], al[4], lane_ref = 0;
+                for (int j = 0; j <= DEPTH_PF; j++) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // v_bfe_i32 takes its bit offset from the word's low five bits (op + the length's lowest bit): op masks repeated at bit 16
-                    const uint32_t len = w[k] >> 4;
-                    rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), w[k], 1u);    // all-ones when the op consumes the reference
-                    al[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(ALN_OPS | (ALN_OPS << 16)), w[k], 1u);    // ... when its bases count toward depth
-                    lane_ref += rl[k];
+                    for (int k = 0; k < 4; k++) w[j][k] = 0;
+                    if ((uint32_t)j < n_chunks) load_chunk((uint32_t)j * (4 * WAVE), w[j]);
                 }
-                const uint32_t incl = wave_incl_sum_dpp(lane_ref);
-                int32_t rel = base_rel + (int32_t)(incl - lane_ref);
+                for (uint32_t c = 0;; c++) {
+                    const uint32_t o0 = c * (4 * WAVE);                             // word offset of this chunk from chunk0
+                    uint32_t nw[4] = {0, 0, 0, 0};
+                    if (c + DEPTH_PF + 1 < n_chunks) load_chunk(o0 + (DEPTH_PF + 1) * (4 * WAVE), nw);
+                    uint32_t (&cur)[4] = w[0];
+                    // only the first and the last chunk of an item can hold words of a neighbouring read
+                    if (!((int32_t)o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
+                        const int32_t o = (int32_t)o0 + lane * 4;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int32_t a = max(rel, 0), b = min(rel + (int32_t)al[k], TW);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
-                    if (a < b) {
-                        atomicAdd(&diff[a], 1u);
-                        atomicAdd(&diff[b], 0xffffffffu);
+                        for (int k = 0; k < 4; k++) if (!((o + k >= c0rel) && ((uint32_t)(o + k) < nrem))) cur[k] = (uint32_t)OP_P;
                     }
-                    rel += (int32_t)rl[k];
-                }
-                base_rel += (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint32_t rl[4], al[4], lane_ref = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) w[k] = w1[k];                           // (stale when !more: the loop ends there)
+                    for (int k = 0; k < 4; k++) {
+                        // v_bfe_i32 takes its bit offset from the word's low five bits (op + the length's lowest bit): op masks repeated at bit 16
+                        const uint32_t len = cur[k] >> 4;
+                        rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), cur[k], 1u);    // all-ones when the op consumes the reference
+                        al[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(ALN_OPS | (ALN_OPS << 16)), cur[k], 1u);    // ... when its bases count toward depth
+                        lane_ref += rl[k];
+                    }
+                    const uint32_t incl = wave_incl_sum_dpp(lane_ref);
+                    int32_t rel = base_rel + (int32_t)(incl - lane_ref);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int32_t a = max(rel, 0), b = min(rel + (int32_t)al[k], TW);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
+                        if (a < b) {
+                            atomicAdd(&diff[a], 1u);
+                            atomicAdd(&diff[b], 0xffffffffu);
+                        }
+                        rel += (int32_t)rl[k];
+                    }
+                    base_rel += (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (c + 1 >= n_chunks || base_rel >= TW) break;                 // the read ends here, or the rest of it lies right of the tile
+#pragma unroll
+                    for (int j = 0; j < DEPTH_PF; j++) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) w[j][k] = w[j + 1][k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) w[DEPTH_PF][k] = nw[k];
+                }
             }
         }
         __syncthreads();
