@@ -91,17 +91,26 @@ namespace csv {
 
 // device scalars written by the scan / depth kernels, read back once per chromosome
 struct ScanCounters {
+    // The three counters that every workgroup of a big kernel adds to sit in cache lines of their own: same-address device atomics
+    // retire one after the other, and a workgroup's epilogue waits for its slot reservation on n_sig (returning) behind whatever
+    // else is queued on that line.
     unsigned long long n_sig;        // all emitted signatures
+    char               pad0[56];
     unsigned long long n_del;        // kind == DEL
+    char               pad1[56];
     unsigned long long depth_sum;
+    char               pad2[56];
     unsigned int       depth_nonzero;
     unsigned int       max_start;    // 0xffffffff if a signature start exceeded scan_start_limit(depth_len), else 0
-    unsigned int       max_len;      // largest bucket of the ordering pass's most-significant-digit split (scan epilogue)
+    unsigned int       max_len;      // largest bucket of the ordering pass's most-significant-digit split if above BK_LOCAL_MAX, else 0 (scan epilogue)
     unsigned int       unsorted;     // != 0 if pos[] is not non-decreasing
     int                min_pts;      // written by the min_pts kernel
     int                pad;
     double             mean_cov;
+    char               pad3[32];
 };
+static_assert(sizeof(ScanCounters) == 256, "the counters head the 256-byte block in front of the bucket tables");
+
 
 #define CSV_HIP(ctx, call)                                                                       \
     do {                                                                                         \
@@ -136,7 +145,7 @@ static inline int bits_of(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } r
 struct ScanExtras {
     uint64_t *tile_range = nullptr;   // [2 * n_tiles], zeroed: candidate read range of every depth tile (see DEPTH_TILE below); coordinate-sorted shards only
     uint32_t  n_tiles = 0;
-    uint32_t *bucket_hist = nullptr;  // [BK_N], zeroed: counts of the ordering pass's most-significant-digit buckets; the largest goes to cnt->max_len
+    uint32_t *bucket_hist = nullptr;  // [BK_N], zeroed: counts of the ordering pass's most-significant-digit buckets; a bucket above BK_LOCAL_MAX is reported in cnt->max_len
     int       type_pos = -1, bucket_shift = 0;
 };
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,

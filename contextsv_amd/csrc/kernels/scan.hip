@@ -14,7 +14,7 @@
 // from LDS (it used to be fetched per read: +22 % load instructions at 1.1 k words per read).
 //
 // Signatures are rare (~1e-3 of ops) so they are staged in a per-workgroup LDS buffer
-// (slots reserved with an LDS compare-and-swap) and flushed with ONE global atomic per workgroup;
+// (each emitting lane reserves its slot with an LDS atomic) and flushed with ONE global atomic per workgroup;
 // a single hot global counter would otherwise serialise the chip. Emission order is arbitrary —
 // the ordering pass (sort.hip) reproduces the reference's addSVCall order afterwards.
 //
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
         uint32_t ref_carry = 0;      // reference bases consumed before this chunk (wave-uniform)
         uint32_t acc_q = 0;          // this lane's share of the query bases consumed before this chunk
         uint32_t acc_skip = 0;       // this lane's share of soft clips skipped by the `continue` at sv_caller.cpp:602-604
+        bool had_skip = false;       // ... any so far (wave-uniform)
         int32_t  qs = -1;            // query_start (wave-uniform, kept in a scalar register)
 
         // Chunks are aligned to 256 words (1 KiB; a chunk boundary is a checkpoint slot). Inside a read everything is 32-bit and
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
             const bool need_q = (qs < 0) || any_big;
             if (need_q) {
                 // ---------------- slow path: query cursors --------------------------------------------------
-                const uint32_t q_carry = wave_total_dpp(acc_q);
+                const uint32_t q_carry = t ? wave_total_dpp(acc_q) : 0u;     // (nothing consumed before the first chunk)
                 const uint32_t incl_q = wave_incl_sum_dpp(lane_q);
                 const uint32_t rp = p0 + ref_carry + (incl_ref - lane_ref);   // reference `pos` before this lane's first op
                 const uint32_t qp = q_carry + (incl_q - lane_q);              // plain query cursor before this lane's first op
@@ -286,50 +287,32 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
                             rpk += rl[k];
                         }
                     }
-                    uint32_t skip_before = wave_total_dpp(acc_skip);
+                    uint32_t skip_before = had_skip ? wave_total_dpp(acc_skip) : 0u;
                     if (__ballot(skipped != 0)) {                 // rare: clip past the contig end
                         skip_before += wave_incl_sum_dpp(lane_skip) - lane_skip;
                         acc_skip += lane_skip;
+                        had_skip = true;
                     }
                     if (__ballot(cand != 0)) {
                         uint32_t rpk = rp, qpk = qp, skk = skip_before;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const bool e = (cand >> k) & 1u;
-                            const uint64_t m = __ballot(e);
-                            if (m) {
-                                const uint32_t n_e = (uint32_t)__popcll(m);
-                                const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+                            if ((cand >> k) & 1u) {               // few lanes, usually one: each reserves its own slot of the workgroup buffer
                                 csv_sig sg;
                                 sg.start = rpk + 1u;
                                 sg.end = sg.start + len[k] - 1u;
                                 sg.read = (uint32_t)r;
                                 const uint32_t kind = (op[k] == OP_I) ? CSV_KIND_INS : (op[k] == OP_D ? CSV_KIND_DEL : CSV_KIND_CLIP);
                                 sg.qpos_kind = ((qpk - skk) << 2) | kind;
-                                // reserve n_e slots of the workgroup buffer (LDS CAS), else go straight to HBM
-                                uint32_t slot = 0xffffffffu;
-                                if (lane == 0) {
-                                    uint32_t old = buf_n;
-                                    while (old + n_e <= SIG_BUF) {
-                                        const uint32_t seen = atomicCAS(&buf_n, old, old + n_e);
-                                        if (seen == old) { slot = old; break; }
-                                        old = seen;
-                                    }
+                                const uint32_t slot = atomicAdd(&buf_n, 1u);
+                                if (slot < SIG_BUF) buf[slot] = sg;
+                                else {                            // buffer full: straight to HBM (buf_n keeps counting; the epilogue clamps it)
+                                    const unsigned long long g = atomicAdd(&cnt->n_sig, 1ull);
+                                    if (g < sig_cap) sig_out[g] = sg;
+                                    if (bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
                                 }
-                                slot = __shfl(slot, 0, 64);
-                                if (slot != 0xffffffffu) {
-                                    if (e) buf[slot + rank] = sg;
-                                } else {
-                                    unsigned long long g = 0;
-                                    if (lane == 0) g = atomicAdd(&cnt->n_sig, (unsigned long long)n_e);
-                                    g = __shfl(g, 0, 64);
-                                    if (e && g + rank < sig_cap) sig_out[g + rank] = sg;
-                                    if (e && bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
-                                }
-                                if (e) {
-                                    my_n_del += (kind == CSV_KIND_DEL);
-                                    my_overflow |= (sg.start >= start_limit);      // start does not fit the sort key (never for sane input)
-                                }
+                                my_n_del += (kind == CSV_KIND_DEL);
+                                my_overflow |= (sg.start >= start_limit);          // start does not fit the sort key (never for sane input)
                             }
                             if ((skipped >> k) & 1u) skk += len[k];
                             rpk += rl[k];
@@ -379,7 +362,7 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
         if (wave_overflow) atomicOr(&blk_overflow, 1u);
     }
     __syncthreads();
-    const uint32_t nb = buf_n;
+    const uint32_t nb = min(buf_n, SIG_BUF);
     if (threadIdx.x == 0) {
         blk_gbase = nb ? atomicAdd(&cnt->n_sig, (unsigned long long)nb) : 0ull;
         if (blk_n_del) atomicAdd(&cnt->n_del, (unsigned long long)blk_n_del);
@@ -394,8 +377,11 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
         if (bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
     }
     if (bucket_hist) {
+        // The host only needs to know whether a bucket outgrew what one wave ranks (BK_LOCAL_MAX: then the radix path orders the
+        // signatures), so nothing is written for ordinary input: twelve thousand waves queueing an atomicMax on the counters' cache
+        // line held up the epilogues' slot reservations on the same line (a plain look at the value first was worse: 2x the kernel).
         my_bucket_max = wave_max(my_bucket_max);
-        if (lane == 0 && my_bucket_max) atomicMax(&cnt->max_len, my_bucket_max);
+        if (lane == 0 && my_bucket_max > BK_LOCAL_MAX) atomicMax(&cnt->max_len, my_bucket_max);
     }
 }
 
