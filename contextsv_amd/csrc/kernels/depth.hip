@@ -254,26 +254,41 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         __syncthreads();
         const uint32_t n_items = wl_n;
         const int32_t TW = (int32_t)(T1 - T0);                                      // tile width in positions
-        for (uint32_t it = depth_grab(&next_item, lane); it < n_items; it = depth_grab(&next_item, lane)) {
+        // How many chunks does a walk need? A chunk boundary is a checkpoint slot, so the checkpoints say exactly where a read's
+        // chunks start on the reference: lane l looks up the start of chunk l + 1 of the item, one vector load — requested while the
+        // PREVIOUS item of this wave is being walked, so nobody waits for it. The walk then fetches no chunk that starts right of the
+        // tile's right edge (DEPTH_PF + 1 chunks are kept in flight — the walk is bound by the bytes its 32 waves per CU keep in
+        // flight more than by anything else —: without the count every (tile, read) pair fetched that many chunks past the edge).
+        auto look_ahead = [&](uint32_t item) -> uint32_t {
+            const uint32_t off = (uint32_t)(lane + 1) * (4 * WAVE);
+            return off < uniform32(wl_nrem[item]) ? ckpt[(uniform64(wl_chunk[item]) + off) >> CKPT_SHIFT] : 0xffffffffu;
+        };
+        uint32_t it = depth_grab(&next_item, lane);
+        uint32_t la = it < n_items ? look_ahead(it) : 0u;
+        while (it < n_items) {
             const uint64_t chunk0 = uniform64(wl_chunk[it]);                        // `it` is wave-uniform: keep the item in scalar registers
             const int32_t c0rel = (int32_t)uniform32((uint32_t)wl_c0rel[it]);
             const uint32_t nrem = uniform32(wl_nrem[it]);
             // Positions are kept relative to the tile's left edge in 32-bit signed arithmetic (coordinates and run lengths are
             // below 2^31, the BAM limit): a run [rel, rel + len) clips to [max(rel,0), min(rel+len, TW)) with one max and one min,
             // and a run with no aligned bases (len masked to 0) clips to nothing, so no separate op test is needed.
-            int32_t base_rel = (int32_t)uniform32(wl_p1[it] + wl_carry[it] - (uint32_t)T0);  // wave-uniform: position of the chunk's first staged word, relative to the tile
-            // The walk is bound by the bytes its 32 waves per CU keep in flight more than by anything else: several chunks are
-            // requested ahead of the one being worked on. (Stopping the prefetch exactly at the tile's right edge — the checkpoints
-            // tell where, one 64-lane look-up per item — removes the quarter of the HBM traffic that lies beyond it and costs more
-            // than it saves: the kernel does not wait for bandwidth.)
+            const int32_t p1rel = (int32_t)uniform32(wl_p1[it] - (uint32_t)T0);     // the read's first position, relative to the tile
+            int32_t base_rel = p1rel + (int32_t)uniform32(wl_carry[it]);            // wave-uniform: position of the chunk's first staged word
+            const uint32_t it_next = depth_grab(&next_item, lane);
             auto load_chunk = [&](uint32_t off, uint32_t (&dst)[4]) {
                 const uint64_t c = chunk0 + off;
                 if (vec_ok && c + 4 * WAVE <= n_cigar) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(cigar + c + (uint64_t)lane * 4); dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
                 } else depth_load4(cigar, n_cigar, vec_ok, c + (uint64_t)lane * 4, dst);
             };
+            uint32_t la_next = 0u;
             {
-                const uint32_t n_chunks = (nrem + 4 * WAVE - 1) / (4 * WAVE);
+                uint32_t n_chunks = (nrem + 4 * WAVE - 1) / (4 * WAVE);
+                {   // chunks after the first that start left of the right edge: a prefix of the lanes (reference offsets do not decrease).
+                    // All 64 looked-up chunks needed: the walk is longer than the look-up reaches and runs to the read's end as before.
+                    const uint32_t n_more = (uint32_t)__popcll(__ballot(la != 0xffffffffu && p1rel + (int32_t)la < TW));
+                    if (n_more < (uint32_t)WAVE) n_chunks = min(n_chunks, n_more + 1u);
+                }
                 uint32_t w[DEPTH_PF + 1][4];
 #pragma unroll
                 for (int j = 0; j <= DEPTH_PF; j++) {
@@ -281,6 +296,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                     for (int k = 0; k < 4; k++) w[j][k] = 0;
                     if ((uint32_t)j < n_chunks) load_chunk((uint32_t)j * (4 * WAVE), w[j]);
                 }
+                if (it_next < n_items) la_next = look_ahead(it_next);                // in flight during this walk
                 for (uint32_t c = 0;; c++) {
                     const uint32_t o0 = c * (4 * WAVE);                             // word offset of this chunk from chunk0
                     uint32_t nw[4] = {0, 0, 0, 0};
@@ -323,6 +339,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                     for (int k = 0; k < 4; k++) w[DEPTH_PF][k] = nw[k];
                 }
             }
+            it = it_next; la = la_next;
         }
         __syncthreads();
     }
