@@ -185,7 +185,6 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
 {
     __shared__ uint32_t diff[DEPTH_TILE + 4];
     __shared__ uint32_t wave_tot[DEPTH_WAVES];
-    __shared__ uint64_t range_s[2];
     __shared__ unsigned long long blk_sum;
     __shared__ unsigned int blk_nz;
     __shared__ unsigned int next_item, wl_n;
@@ -198,14 +197,12 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     const uint64_t T0 = (uint64_t)blockIdx.x * DEPTH_TILE;
     const uint64_t T1 = min(T0 + (uint64_t)DEPTH_TILE, (uint64_t)depth_len);
 
+    // candidate range of this tile (left by the scan, or by depth_ranges_kernel): a workgroup-uniform address, so a scalar load that
+    // is in flight while the tile's difference array is zeroed; the first barrier of the batch loop below covers both
+    const uint64_t k_lo = ~tile_range[2 * (uint64_t)blockIdx.x];
+    const uint64_t k_hi = max(k_lo, (uint64_t)tile_range[2 * (uint64_t)blockIdx.x + 1]);
     for (int i = threadIdx.x; i < DEPTH_TILE + 4; i += DEPTH_THREADS) diff[i] = 0;
-    // candidate range of this tile, precomputed for all tiles by depth_ranges_kernel (one load instead of two searches)
-    if (threadIdx.x == 0) {
-        range_s[0] = ~tile_range[2 * (uint64_t)blockIdx.x]; range_s[1] = tile_range[2 * (uint64_t)blockIdx.x + 1];
-        blk_sum = 0; blk_nz = 0;
-    }
-    __syncthreads();
-    const uint64_t k_lo = range_s[0], k_hi = max(range_s[0], range_s[1]);
+    if (threadIdx.x == 0) { blk_sum = 0; blk_nz = 0; }
 
     // Work list: the candidates are examined ONCE per tile by all threads together — thread t takes candidate t of the
     // batch, loads its metadata (coalesced across threads), drops reads that end left of the tile or fail the depth filter
@@ -218,29 +215,41 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         const uint64_t kk = cb + threadIdx.x;
         if (threadIdx.x < WL_CAP && kk < k_hi) {
             const uint64_t r = ord ? (uint64_t)ord[kk] : kk;
+            // everything a candidate needs first is requested together (one round trip), the checkpoint probes are the second, and the
+            // reference offset of the start boundary is the value the last successful probe returned: two dependent round trips per tile
             const uint64_t c0 = cigar_off[r], c1 = cigar_off[r + 1];
             const uint32_t fl = flag[r];
-            const bool ok = ((int64_t)ref_end[r] >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && c1 > c0;
+            const int32_t r_end = ref_end[r], r_pos = pos[r];
+            const bool ok = ((int64_t)r_end >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && c1 > c0;
             if (ok) {
-                const uint64_t p1 = (uint64_t)(uint32_t)((uint32_t)pos[r] + 1u);    // 1-based first reference position, in uint32 as there (:498): pos -1 wraps to 0
+                const uint64_t p1 = (uint64_t)(uint32_t)((uint32_t)r_pos + 1u);     // 1-based first reference position, in uint32 as there (:498): pos -1 wraps to 0
                 const uint64_t g0 = c0 >> CKPT_SHIFT, g1 = (c1 - 1) >> CKPT_SHIFT;
                 uint64_t lo = g0 + 1, hi = g1 + 1;                                   // first boundary NOT left of the tile
+                uint32_t lo_val = 0;                                                 // ckpt[lo - 1] whenever lo has moved
                 // The reference offset grows almost linearly with the word index, so the boundary is guessed by interpolation and
                 // three independent probes around the guess usually close the bracket: one round trip where a bisection of the
                 // read's ~20 checkpoints is five dependent ones (this search sits on every tile's critical path).
                 if (lo < hi && p1 <= T0) {
-                    const uint64_t rlen = (uint64_t)((int64_t)ref_end[r] - (int64_t)p1 + 1);
+                    const uint64_t rlen = (uint64_t)((int64_t)r_end - (int64_t)p1 + 1);
                     uint64_t guess = lo + (uint64_t)((double)(T0 - p1) / (double)(rlen ? rlen : 1) * (double)(hi - lo));
                     guess = min(max(guess, lo), hi - 1);
                     const uint64_t ga = guess > lo ? guess - 1 : lo, gb = guess, gc = min(guess + 1, hi - 1);
                     const uint32_t ka = ckpt[ga], kb = ckpt[gb], kc = ckpt[gc];
                     // f(g) = (p1 + ckpt[g] <= T0) is true up to the answer and false from it on
-                    if (p1 + kc <= T0) lo = gc + 1;
-                    else { hi = gc; if (p1 + kb <= T0) lo = gb + 1; else { hi = gb; if (p1 + ka <= T0) lo = ga + 1; else hi = ga; } }
+                    if (p1 + kc <= T0) { lo = gc + 1; lo_val = kc; }
+                    else {
+                        hi = gc;
+                        if (p1 + kb <= T0) { lo = gb + 1; lo_val = kb; }
+                        else { hi = gb; if (p1 + ka <= T0) { lo = ga + 1; lo_val = ka; } else hi = ga; }
+                    }
                 }
-                while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (p1 + ckpt[mid] <= T0) lo = mid + 1; else hi = mid; }
+                while (lo < hi) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    const uint32_t v = ckpt[mid];
+                    if (p1 + v <= T0) { lo = mid + 1; lo_val = v; } else hi = mid;
+                }
                 uint64_t chunk = c0 & ~(uint64_t)(CKPT_WORDS - 1); uint32_t carry = 0;     // walks start on a checkpoint: at most 63 words re-read
-                if (lo > g0 + 1) { chunk = (lo - 1) << CKPT_SHIFT; carry = ckpt[lo - 1]; }
+                if (lo > g0 + 1) { chunk = (lo - 1) << CKPT_SHIFT; carry = lo_val; }
                 if (p1 + carry < T1) {                                               // else the whole read lies right of the tile
                     const uint32_t slot = atomicAdd(&wl_n, 1u);
                     wl_chunk[slot] = chunk;
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         __syncthreads();
     }
 
+    if (k_lo >= k_hi) __syncthreads();       // no batch ran (empty tile): the zeroing above has not met a barrier yet
     // scan the difference array: wave w owns entries [w*DEPTH_PER_WAVE, (w+1)*DEPTH_PER_WAVE)
     const int w_base = wave * DEPTH_PER_WAVE;
     uint32_t tot = 0;
