@@ -109,7 +109,7 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     unsigned long long *__restrict__ tile_range, uint32_t n_tiles, uint32_t *__restrict__ bucket_hist, int hist_type_pos, int hist_shift)
 {
     __shared__ csv_sig buf[SIG_BUF];
-    __shared__ uint32_t ring[SCAN_WAVES][RING_D][CHUNK_WORDS];
+    __shared__ alignas(16) uint32_t ring[SCAN_WAVES][RING_D][CHUNK_WORDS];      // 16-byte aligned: LDS-DMA destination and ds_read_b128 source
     __shared__ uint32_t buf_n, blk_n_del, blk_overflow;
     __shared__ unsigned long long blk_gbase;
 
