@@ -119,47 +119,6 @@ __device__ __forceinline__ Staged<M> stage_tile(const M &m, typename M::Elem *sh
     return Staged<M>{sh, first, m};
 }
 
-// Two independent point sets can share every launch: positions [0, split) are one set, [split, n) the other (the DEL
-// and INS calls of a chromosome). A window never leaves its own set; cluster ids restart at 0 in the second set.
-// A window holds a few dozen candidates and its loop is a chain of dependent steps, so one thread per point leaves the chip
-// idle (n / 64 waves for n ~ 1e5): DB_G lanes share a point and stride its window together.
-template <class M>
-__global__ void __launch_bounds__(DB_THREADS) db_count_kernel(M m, uint64_t n, uint64_t split, int min_pts_imm, const int *__restrict__ d_min_pts,
-                                const uint32_t *__restrict__ oid, uint8_t *__restrict__ core, uint32_t *__restrict__ parent,
-                                uint32_t *__restrict__ is_root, unsigned int *__restrict__ ticket)
-{
-    __shared__ typename M::Elem sh[UF_TILE + 2 * DB_HALO];
-    const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE;
-    const Staged<M> at = stage_tile(m, sh, t0, n);
-    if (t0 + threadIdx.x == n) { is_root[n] = 0; *ticket = 0; }
-    const int min_pts = d_min_pts ? *d_min_pts : min_pts_imm;
-    const uint32_t g = threadIdx.x / DB_G, lane = threadIdx.x % DB_G;
-    for (uint32_t li = g; li < UF_TILE; li += DB_GROUPS) {
-        const uint64_t i = t0 + li;
-        if (i >= n) break;
-        const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
-        const typename M::Elem mine = at(i);
-        uint64_t lo, hi;
-        m.window(mine, lo, hi);
-        int cnt = 0;
-        for (uint64_t j0 = i; j0 < s1 && (uint64_t)M::key(at(j0)) <= hi; j0 += DB_G) {        // j0 == i: the point itself
-            const uint64_t j = j0 + lane;
-            if (j < s1) { const typename M::Elem o = at(j); if ((uint64_t)M::key(o) <= hi) cnt += m.nb(mine, o); }
-        }
-        for (uint64_t b0 = i; b0 > s0 && (uint64_t)M::key(at(b0 - 1)) >= lo; b0 = b0 > DB_G ? b0 - DB_G : 0) {
-            if (b0 >= (uint64_t)lane + 1 && b0 - 1 - lane >= s0) { const typename M::Elem o = at(b0 - 1 - lane); if ((uint64_t)M::key(o) >= lo) cnt += m.nb(mine, o); }
-            if (b0 <= DB_G) break;
-        }
-        cnt = group_sum(cnt);
-        if (lane == 0) {
-            const uint32_t me = oid ? oid[i] : (uint32_t)i;
-            parent[me] = me;                           // union-find + root flags start here (no separate init launch)
-            is_root[me] = 0;
-            core[i] = cnt >= min_pts;
-        }
-    }
-}
-
 __device__ __forceinline__ uint32_t uf_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
@@ -198,14 +157,17 @@ __device__ __forceinline__ uint32_t lds_find(uint32_t *lpar, uint32_t x)
     }
 }
 
-// Pairs with both ends in one tile of UF_TILE consecutive positions: union-find in LDS (a cluster's members are neighbours in
-// the sorted order, so this is nearly every pair), then each core point's parent is written flat: parent[me] = its tile root.
+// Two independent point sets can share every launch: positions [0, split) are one set, [split, n) the other (the DEL
+// and INS calls of a chromosome). A window never leaves its own set; cluster ids restart at 0 in the second set.
+// A window holds a few dozen candidates and its loop is a chain of dependent steps, so one thread per point leaves the chip
+// idle (n / 64 waves for n ~ 1e5): DB_G lanes share a point and stride its window together.
 template <class M>
-__global__ void __launch_bounds__(DB_THREADS) db_union_local_kernel(M m, uint64_t n, uint64_t split, const uint8_t *__restrict__ core,
-                                                                    const uint32_t *__restrict__ oid, uint32_t *__restrict__ parent)
+__global__ void __launch_bounds__(DB_THREADS) db_count_union_kernel(M m, uint64_t n, uint64_t split, int min_pts_imm, const int *__restrict__ d_min_pts,
+                                const uint32_t *__restrict__ oid, uint8_t *__restrict__ core, uint32_t *__restrict__ parent,
+                                uint32_t *__restrict__ is_root, unsigned int *__restrict__ ticket)
 {
+    __shared__ typename M::Elem sh[UF_TILE + 2 * DB_HALO];
     __shared__ uint32_t lpar[UF_TILE], loid[UF_TILE];
-    __shared__ typename M::Elem sh[UF_TILE];
     __shared__ uint8_t lcore[UF_TILE];
     const uint64_t t0 = (uint64_t)blockIdx.x * UF_TILE;
     if (threadIdx.x < UF_TILE) {
@@ -213,23 +175,54 @@ __global__ void __launch_bounds__(DB_THREADS) db_union_local_kernel(M m, uint64_
         const uint64_t i = t0 + li;
         lpar[li] = li;
         loid[li] = i < n ? (oid ? oid[i] : (uint32_t)i) : NONE;
-        lcore[li] = i < n ? core[i] : 0;
-        if (i < n) sh[li] = m.load(i);
+        lcore[li] = 0;
+    }
+    const Staged<M> at = stage_tile(m, sh, t0, n);         // (ends with a barrier)
+    if (t0 + threadIdx.x == n) { is_root[n] = 0; *ticket = 0; }
+    const int min_pts = d_min_pts ? *d_min_pts : min_pts_imm;
+    const uint32_t g = threadIdx.x / DB_G, lane = threadIdx.x % DB_G;
+    // ---- core points: |window neighbours| >= min_pts ----
+    for (uint32_t li = g; li < UF_TILE; li += DB_GROUPS) {
+        const uint64_t i = t0 + li;
+        if (i >= n) break;
+        const uint64_t s0 = i < split ? 0 : split, s1 = i < split ? split : n;
+        const typename M::Elem mine = at(i);
+        uint64_t lo, hi;
+        m.window(mine, lo, hi);
+        int cnt = 0;
+        for (uint64_t j0 = i; j0 < s1 && (uint64_t)M::key(at(j0)) <= hi; j0 += DB_G) {        // j0 == i: the point itself
+            const uint64_t j = j0 + lane;
+            if (j < s1) { const typename M::Elem o = at(j); if ((uint64_t)M::key(o) <= hi) cnt += m.nb(mine, o); }
+        }
+        for (uint64_t b0 = i; b0 > s0 && (uint64_t)M::key(at(b0 - 1)) >= lo; b0 = b0 > DB_G ? b0 - DB_G : 0) {
+            if (b0 >= (uint64_t)lane + 1 && b0 - 1 - lane >= s0) { const typename M::Elem o = at(b0 - 1 - lane); if ((uint64_t)M::key(o) >= lo) cnt += m.nb(mine, o); }
+            if (b0 <= DB_G) break;
+        }
+        cnt = group_sum(cnt);
+        if (lane == 0) {
+            const uint32_t me = loid[li];
+            parent[me] = me;                           // union-find + root flags start here (no separate init launch)
+            is_root[me] = 0;
+            core[i] = cnt >= min_pts;
+            lcore[li] = cnt >= min_pts;
+        }
     }
     __syncthreads();
-    const uint32_t g = threadIdx.x / DB_G, lane = threadIdx.x % DB_G;
+    // ---- pairs with both ends in this tile: union-find in LDS (a cluster's members are neighbours in the sorted order, so this is
+    // nearly every pair), then each core point's parent is written flat: parent[me] = its tile root ----
+    typename M::Elem *tile = sh + DB_HALO;                  // the tile's own points inside the staged window
     for (uint32_t li = g; li < UF_TILE; li += DB_GROUPS) {
         if (!lcore[li]) continue;
         const uint64_t i = t0 + li;
-        const typename M::Elem mine = sh[li];
+        const typename M::Elem mine = tile[li];
         uint64_t lo, hi;
         m.window(mine, lo, hi);
         const uint64_t s1 = i < split ? split : n;
         const uint32_t l_end = (uint32_t)(min(t0 + UF_TILE, s1) - t0);
-        for (uint32_t j0 = li + 1; j0 < l_end && (uint64_t)M::key(sh[j0]) <= hi; j0 += DB_G) {
+        for (uint32_t j0 = li + 1; j0 < l_end && (uint64_t)M::key(tile[j0]) <= hi; j0 += DB_G) {
             const uint32_t lj = j0 + lane;
             if (lj >= l_end) continue;
-            const typename M::Elem o = sh[lj];
+            const typename M::Elem o = tile[lj];
             if ((uint64_t)M::key(o) > hi || !lcore[lj] || !m.nb(mine, o)) continue;
             uint32_t a = li, b = lj;
             for (;;) {
@@ -418,8 +411,7 @@ static void run_dbscan(hipStream_t s, M m, const uint32_t *oid, uint64_t n, uint
     unsigned int *ticket = (unsigned int *)p;
     const dim3 grid((unsigned)((n + 255) / 256)), grid1((unsigned)((n + 1 + 255) / 256)), blk(256);
     const dim3 wide(DB_THREADS);
-    hipLaunchKernelGGL(db_count_kernel<M>, grid1, wide, 0, s, m, n, split, min_pts, d_min_pts, oid, core, parent, cid, ticket);
-    hipLaunchKernelGGL(db_union_local_kernel<M>, grid, wide, 0, s, m, n, split, core, oid, parent);
+    hipLaunchKernelGGL(db_count_union_kernel<M>, grid1, wide, 0, s, m, n, split, min_pts, d_min_pts, oid, core, parent, cid, ticket);
     hipLaunchKernelGGL(db_union_cross_kernel<M>, grid, blk, 0, s, m, n, split, core, oid, parent);
     if (!oid) {
         hipLaunchKernelGGL(db_roots_rank_kernel, dim3(n_tiles), dim3(UF_TILE), 0, s, n, core, parent, root_of, cid, tile_count, tile_prefix, ticket, n_tiles);
