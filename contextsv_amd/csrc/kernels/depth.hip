@@ -183,7 +183,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     const uint32_t *__restrict__ ckpt,       // reference offset of the owning read at every CKPT_WORDS-word boundary (scan.hip)
     uint32_t depth_len, uint32_t *__restrict__ depth, ScanCounters *__restrict__ cnt)
 {
-    __shared__ uint32_t diff[DEPTH_TILE + 4];
+    __shared__ alignas(16) uint32_t diff[DEPTH_TILE + 4];
     __shared__ uint32_t wave_tot[DEPTH_WAVES];
     __shared__ unsigned long long blk_sum;
     __shared__ unsigned int blk_nz;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     // is in flight while the tile's difference array is zeroed; the first barrier of the batch loop below covers both
     const uint64_t k_lo = ~tile_range[2 * (uint64_t)blockIdx.x];
     const uint64_t k_hi = max(k_lo, (uint64_t)tile_range[2 * (uint64_t)blockIdx.x + 1]);
-    for (int i = threadIdx.x; i < DEPTH_TILE + 4; i += DEPTH_THREADS) diff[i] = 0;
+    for (int i = threadIdx.x * 4; i < DEPTH_TILE + 4; i += DEPTH_THREADS * 4) *reinterpret_cast<uint4 *>(&diff[i]) = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x == 0) { blk_sum = 0; blk_nz = 0; }
 
     // Work list: the candidates are examined ONCE per tile by all threads together — thread t takes candidate t of the
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         const uint4 v = *reinterpret_cast<const uint4 *>(&diff[w_base + rd * 4 * WAVE + lane * 4]);
         tot += v.x + v.y + v.z + v.w;
     }
-    tot = wave_sum(tot);
+    tot = wave_total_dpp(tot);
     if (lane == 0) wave_tot[wave] = tot;
     __syncthreads();
     uint32_t carry = 0;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         const int off = w_base + rd * 4 * WAVE + lane * 4;
         const uint4 v = *reinterpret_cast<const uint4 *>(&diff[off]);
         const uint32_t l0 = v.x, l1 = l0 + v.y, l2 = l1 + v.z, l3 = l2 + v.w;
-        const uint32_t incl = wave_incl_sum(l3);
+        const uint32_t incl = wave_incl_sum_dpp(l3);
         const uint32_t pre = carry + (incl - l3);
         uint4 d;
         d.x = pre + l0; d.y = pre + l1; d.z = pre + l2; d.w = pre + l3;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         if (g + 1 < T1) { my_sum += d.y; my_nz += d.y > 0; }
         if (g + 2 < T1) { my_sum += d.z; my_nz += d.z > 0; }
         if (g + 3 < T1) { my_sum += d.w; my_nz += d.w > 0; }
-        carry += __shfl(incl, 63, 64);
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     my_sum = wave_sum64(my_sum);
     my_nz = wave_sum(my_nz);
