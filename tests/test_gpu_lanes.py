@@ -138,3 +138,35 @@ def test_wrapped_device_arrays_run_the_same_pipeline_and_bad_offsets_are_refused
         for p in held:
             hip.hipFree(p)
         syn.free()
+
+
+def test_three_lanes_as_the_benchmark_runs_them(ctx):
+    """bench.py's default: three contexts behind one gate, the same contig resident once per lane, unequal step counts — every lane's
+    last result equals the single-context result, and the per-lane call totals add up."""
+    syn = host.SynthShard(seed=31, chr_len=2_500_000, depth=25.0, tech=0, threads=4)
+    ctxs = [ctx, cs.Context(0), cs.Context(0)]
+    gate = cs.Gate()
+    shards = []
+    try:
+        sh = ctx.upload(syn.reads, syn.depth_len)
+        want, _, st1 = host.process_resident_chromosome(ctx, sh, 0.1, 0.1)
+        sh.free()
+        for c in ctxs:
+            c.set_gate(gate)
+            c.timing_enable(2); c.timing_reset()
+        shards = [c.upload(syn.reads, syn.depth_len) for c in ctxs]
+        for steps in ([4, 4, 4], [7, 1, 3], [1, 5, 2]):
+            got, st, ms, total = host.process_resident_lanes(ctxs, shards, steps, 0.1, 0.1)
+            assert st.n_signatures == st1.n_signatures and st.depth_sum == st1.depth_sum
+            assert got.tobytes() == want.tobytes() and total == sum(steps) * len(want) and len(want) > 10
+        assert sum(c.timing()["depth"][1] for c in ctxs) == 12 + 11 + 8
+    finally:
+        for c in ctxs:
+            c.timing_enable(0)
+            c.set_gate(None)
+        for s_ in shards:
+            s_.free()
+        for c in ctxs[1:]:
+            c.close()
+        gate.close()
+        syn.free()
