@@ -140,6 +140,10 @@ def main():
         for c in lane_ctx:
             c.synchronize()
 
+    # setup, like the upload: every lane's page-locked result buffers (three per lane, pooled by its context) exist before anything is
+    # timed or counted as warm-up — a first use inside the timed region costs a hipHostMalloc and a capacity round trip per buffer
+    if n_lanes > 1:
+        job(3 * n_lanes)
     if args.warmup:
         job(args.warmup)
     for c in lane_ctx:

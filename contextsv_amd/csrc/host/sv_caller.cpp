@@ -8,6 +8,7 @@
 #include <mutex>
 #include <thread>
 #include <stdexcept>
+#include <atomic>
 
 #include "dbscan.h"
 #include "log.h"
@@ -88,6 +89,19 @@ void SVCaller::mergeSignaturesWithLabels(const csv_sig *sig, const int32_t *labe
     }
 }
 
+// How many signatures did the chromosomes of this process need room for so far? New result buffers start at that size: a buffer that
+// turns out too small costs a CSV_ECAPACITY round trip (grow + synchronous fetch), and a driver that is called once per batch of
+// chromosomes would pay it again for every buffer of every call (3 lanes x 3 buffers x ~1 ms per call of the benchmark).
+namespace {
+std::atomic<uint64_t> g_result_hint{0};
+uint64_t result_capacity_hint(const csv_ctx *) { return std::max<uint64_t>(1 << 16, g_result_hint.load(std::memory_order_relaxed)); }
+void note_result_size(const csv_ctx *, uint64_t n_sig)
+{
+    uint64_t h = g_result_hint.load(std::memory_order_relaxed);
+    while (n_sig > h && !g_result_hint.compare_exchange_weak(h, n_sig, std::memory_order_relaxed)) {}
+}
+}  // namespace
+
 void SVCaller::DeviceOut::reserve(csv_ctx *c, uint64_t n)
 {
     if (n <= cap && c == ctx) return;
@@ -104,13 +118,14 @@ void SVCaller::runDeviceChain(const std::string &chr, csv_shard *shard, double e
 {
     const double t0 = now_ms();
     csv_chr_result res;
-    if (!out.cap) out.reserve(ctx, 1 << 16);
+    if (!out.cap) out.reserve(ctx, result_capacity_hint(ctx));
     int rc = csvgpu_chr_pipeline_fetch(ctx, shard, (uint32_t)min_oplen, (uint8_t)min_mapq, eps, pct, &res, out.sig, out.lab, out.cap);
     if (rc == CSV_ECAPACITY) {                         // first contig of this size: grow the buffers, fetch what the device already holds
         out.reserve(ctx, res.n_sig);
         rc = csvgpu_chr_fetch(ctx, shard, &res, out.sig, out.lab);
     }
     check(ctx, rc, "processChromosome");
+    note_result_size(ctx, res.n_sig);
     st.n_signatures = res.n_sig; st.n_del = res.n_del; st.n_ins = res.n_ins;
     st.depth_sum = res.depth_sum; st.depth_nonzero = res.depth_nonzero; st.mean_chr_cov = res.mean_cov; st.dbscan_min_pts = res.min_pts;
     if (pct > 0.0)
@@ -213,7 +228,7 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
             const double t0 = now_ms();
             DeviceOut &out = slot[i % kSlots];
             ChrStats &st = stats[i];
-            if (!out.cap) out.reserve(ctx, 1 << 16);
+            if (!out.cap) out.reserve(ctx, result_capacity_hint(ctx));
             csv_job *job = ahead;
             ahead = nullptr;
             int rc = csvgpu_chr_job_cluster(ctx, job, eps, out.sig, out.lab, out.cap);
@@ -231,6 +246,7 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
                 rc = csvgpu_chr_fetch(ctx, shards[i], &res, out.sig, out.lab);
             }
             check(ctx, rc, "processChromosome");
+            note_result_size(ctx, res.n_sig);
             st.n_signatures = res.n_sig; st.n_del = res.n_del; st.n_ins = res.n_ins;
             st.depth_sum = res.depth_sum; st.depth_nonzero = res.depth_nonzero; st.mean_chr_cov = res.mean_cov; st.dbscan_min_pts = res.min_pts;
             out.n_del = res.n_del; out.n_ins = res.n_ins;
