@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-file", action="store_true", help="skip the BAM-staged from-file measurement")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after the other (step latency)")
-    ap.add_argument("--lanes", type=int, default=3, help="chromosomes in flight per GPU (contexts sharing a gate: their scan + depth pairs run back "
+    ap.add_argument("--lanes", type=int, default=0, help="0 = 3, or 1 for runs of fewer than 10 steps (a call of the lanes driver costs 1.6 ms + 0.385 ms per step, the one-lane driver 0.7 ms + 0.52: tools/lanes_probe.py). Chromosomes in flight per GPU (contexts sharing a gate: their scan + depth pairs run back "
                     "to back on the gate's stream, their small kernels beside them); the big kernels stretch by ~10 %% under the co-running "
                     "small ones, the throughput gains ~25 %% over one lane; four lanes are slower again")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timers around every kernel group, not only scan and depth")
@@ -100,7 +100,7 @@ def main():
     ctx.synchronize()
     t_upload = time.time() - t0
     # further lanes: their own context (stream, arenas) and their own resident copy of the contig, as a second chromosome would be
-    n_lanes = 1 if args.no_pipeline else max(1, args.lanes)
+    n_lanes = 1 if args.no_pipeline else (args.lanes if args.lanes > 0 else (3 if args.steps >= 10 else 1))
     lane_ctx, lane_shard = [ctx], [shard]
     gate = cs.Gate() if n_lanes > 1 else None
     for _ in range(1, n_lanes):
