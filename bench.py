@@ -173,6 +173,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # per-kernel device time from HIP events recorded on the kernels' own stream, inside the timed region
         kern = {k: ms / args.steps for k, (ms, n) in timing.items()}        # per step: a group may span several timer scopes (ordering: pre-pass + sort)
+        for k in ("cigar_scan", "depth"):                                   # one launch per step each; behind a gate only every fourth pair carries timers
+            if k in timing and timing[k][1] > 0:
+                kern[k] = timing[k][0] / timing[k][1]
+        timed_launches = {k: int(timing[k][1]) for k in ("cigar_scan", "depth") if k in timing}
         # dbscan group = two fits (DEL + INS) per step in one timer scope; scan/depth/sort one scope per step
         alg_bytes = {
             "cigar_scan": 4.0 * reads.n_cigar + 23.0 * reads.n_reads + 16.0 * st.n_signatures,
@@ -220,6 +224,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes[dominant], "kernel_ms": kern.get(dominant, 0.0),
+                         "launches_timed": timed_launches.get(dominant, 0), "launches": args.steps,
                          "all": {k: {"ms": round(kern.get(k, 0.0), 5), "GBps": round(alg_bytes[k] / (kern[k] * 1e-3) / 1e9, 2) if kern.get(k, 0) > 0 else None}
                                  for k in alg_bytes}},
         }

@@ -55,6 +55,7 @@ struct csv_ctx {
     void        *pinned = nullptr;          // small pinned host block for scalar read-backs
     size_t       pinned_cap = 0;
     int          timing = 0;                // 0 off, 1 every kernel group, 2 only the two bandwidth-bound groups (scan, depth)
+    uint32_t     timer_tick = 0;            // jobs seen by the pair timers (level 2 times every fourth pair on a gate's stream)
     std::vector<csv::Timer> timers;         // recorded, not yet folded
     std::vector<hipEvent_t> event_pool;
     double       t_ms[CSV_K_COUNT] = {0};

@@ -115,7 +115,7 @@ const char *csvgpu_last_error(const csv_ctx *ctx);
 int         csvgpu_synchronize(csv_ctx *ctx);
 /* Per-kernel timers: when enabled, each launch group is bracketed by HIP events recorded on
  * the stream the group runs on (the context's; for the scan + depth pair of a job behind a gate, the gate's — there the
- * pair shares three events); csvgpu_timing_get() synchronises and returns the accumulated device
+ * pair shares three events, and at on = 2 only every fourth pair is timed); csvgpu_timing_get() synchronises and returns the accumulated device
  * time and the number of launch groups since the last reset. on = 1: every group; on = 2: only CSV_K_CIGAR_SCAN and
  * CSV_K_DEPTH (an event is a barrier packet in the queue, ~5 us of idle device each); on = 0: off. */
 int         csvgpu_timing_enable(csv_ctx *ctx, int on);

@@ -37,7 +37,8 @@ def test_lanes_give_the_single_context_result(ctx):
                 assert total == steps[0] * len(want[0][0]) + steps[1] * len(want[1][0])
         for c, n_steps in ((ctx, 2 * (3 + 5)), (ctx2, 2 * (3 + 2))):
             t = c.timing()
-            assert t["cigar_scan"][1] == n_steps and t["depth"][1] == n_steps and t["cigar_scan"][0] > 0 and t["depth"][0] > 0
+            timed = (n_steps + 3) // 4                   # level 2 behind a gate: every fourth pair carries the timers
+            assert t["cigar_scan"][1] == timed and t["depth"][1] == timed and t["cigar_scan"][0] > 0 and t["depth"][0] > 0
     finally:
         for c in (ctx, ctx2):
             c.timing_enable(0)
@@ -159,7 +160,7 @@ def test_three_lanes_as_the_benchmark_runs_them(ctx):
             got, st, ms, total = host.process_resident_lanes(ctxs, shards, steps, 0.1, 0.1)
             assert st.n_signatures == st1.n_signatures and st.depth_sum == st1.depth_sum
             assert got.tobytes() == want.tobytes() and total == sum(steps) * len(want) and len(want) > 10
-        assert sum(c.timing()["depth"][1] for c in ctxs) == 12 + 11 + 8
+        assert [c.timing()["depth"][1] for c in ctxs] == [(n + 3) // 4 for n in (4 + 7 + 1, 4 + 1 + 5, 4 + 3 + 2)]      # every fourth pair is timed
     finally:
         for c in ctxs:
             c.timing_enable(0)
