@@ -73,6 +73,8 @@ ABI = {
     "csvgpu_chr_job_begin": (_P, [_P, _P, C.c_uint32, C.c_uint8, C.c_double]),
     "csvgpu_chr_job_cluster": (C.c_int, [_P, _P, C.c_double, _P, _P, C.c_uint64]),
     "csvgpu_chr_job_end": (C.c_int, [_P, _P, C.POINTER(csv_chr_result)]),
+    "csvgpu_chr_job_abort": (C.c_int, [_P, _P]),
+    "csvgpu_test_fail_next_alloc": (None, [C.c_int]),
     "csvgpu_gate_create": (_P, []),
     "csvgpu_gate_destroy": (None, [_P]),
     "csvgpu_set_gate": (C.c_int, [_P, _P]),

@@ -67,6 +67,7 @@ struct csv_ctx {
     csv_gate    *gate = nullptr;
     char        *job_pin = nullptr;         // page-locked counter slots of the jobs in flight (csvgpu_chr_job_*)
     size_t       job_pin_next = 0;
+    uint32_t     job_pin_busy = 0;          // bit i: slot i belongs to a job between begin and end / abort
 };
 
 struct csv_shard {

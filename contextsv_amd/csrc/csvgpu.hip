@@ -11,6 +11,8 @@
 namespace csv {
 
 static std::string g_create_err;
+int g_fail_alloc = 0;                                  // csvgpu_test_fail_next_alloc
+static inline bool csv_test_fail_alloc() { if (g_fail_alloc > 0) { g_fail_alloc--; return true; } return false; }
 
 int arena_reserve(csv_ctx *ctx, Arena &a, size_t bytes)
 {
@@ -975,13 +977,25 @@ struct csv_job {
     int32_t *labels = nullptr;
 };
 
+// CSV_MAX_JOBS rotating 512-byte page-locked slots per context; a slot belongs to its job from begin to end / abort, so a caller
+// that holds more than CSV_MAX_JOBS jobs open on one context is refused instead of aliasing another job's counters.
 static char *job_pin_slot(csv_ctx *ctx)
 {
-    constexpr size_t kSlots = 16, kSlot = 512;
+    constexpr size_t kSlots = CSV_MAX_JOBS, kSlot = 512;
     if (!ctx->job_pin && hipHostMalloc((void **)&ctx->job_pin, kSlots * kSlot, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    char *p = ctx->job_pin + (ctx->job_pin_next % kSlots) * kSlot;
-    ctx->job_pin_next++;
-    return p;
+    for (size_t k = 0; k < kSlots; k++) {
+        const size_t i = (ctx->job_pin_next + k) % kSlots;
+        if (ctx->job_pin_busy & (1u << i)) continue;
+        ctx->job_pin_busy |= 1u << i;
+        ctx->job_pin_next = i + 1;
+        return ctx->job_pin + i * kSlot;
+    }
+    return nullptr;
+}
+static void job_pin_release(csv_ctx *ctx, char *p)
+{
+    if (!p || !ctx->job_pin) return;
+    ctx->job_pin_busy &= ~(1u << (size_t)((p - ctx->job_pin) / 512));
 }
 
 // scan (+ counters on their way to the host + depth pass, when the shard's sortedness is known). For a coordinate-sorted shard the
@@ -1078,6 +1092,7 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
 static void job_free(csv_ctx *ctx, csv_job *job)
 {
     if (!job) return;
+    job_pin_release(ctx, job->pin);
     if (job->ev_zero) ctx->event_pool.push_back(job->ev_zero);
     if (job->ev_scan) ctx->event_pool.push_back(job->ev_scan);
     if (job->ev_depth) ctx->event_pool.push_back(job->ev_depth);
@@ -1095,6 +1110,7 @@ csv_job *csvgpu_chr_job_begin(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, u
     job->sh = sh; job->min_oplen = min_oplen; job->min_mapq = min_mapq; job->min_pts_pct = min_pts_pct;
     job->ev_zero = get_event(ctx); job->ev_scan = get_event(ctx); job->ev_depth = get_event(ctx); job->ev_mid = get_event(ctx); job->ev_done = get_event(ctx);
     job->pin = job_pin_slot(ctx);
+    if (!job->pin && ctx->job_pin) { ctx->err = "job: more than CSV_MAX_JOBS jobs open on this context"; job_free(ctx, job); return nullptr; }
     if (!job->pin || !job->ev_zero || !job->ev_scan || !job->ev_depth || !job->ev_mid || !job->ev_done) { ctx->err = "job: cannot allocate events / page-locked memory"; job_free(ctx, job); return nullptr; }
     if (arena_reserve(ctx, ctx->work, depth_chain_bytes(sh->d.n_reads, sh->depth_len)) || job_queue_front(ctx, job)) { job_free(ctx, job); return nullptr; }
     return job;
@@ -1122,9 +1138,17 @@ int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host
         if (h.n_sig <= sh->sig_cap) break;
         if (attempt) { ctx->err = "pipeline: signature buffer overflow twice"; return CSV_ENOMEM; }
         CSV_HIP(ctx, hipStreamSynchronize(s));                            // the queued depth pass reads what the re-run scan rewrites
-        CSV_HIP(ctx, hipFree(sh->sig_raw));
-        sh->sig_raw = nullptr; sh->sig_cap = h.n_sig + h.n_sig / 8 + 1024;
-        CSV_HIP(ctx, hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)));
+        // the larger buffer first: if it cannot be had, the shard keeps its old buffer AND its old capacity (a later job on this
+        // shard must never see a capacity without a buffer behind it — the scan's `g < sig_cap` guard would write through null)
+        const uint64_t new_cap = h.n_sig + h.n_sig / 8 + 1024;
+        csv_sig *bigger = nullptr;
+        if (csv_test_fail_alloc() || hipMalloc((void **)&bigger, new_cap * sizeof(csv_sig)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->err = "hipMalloc failed (signature buffer)";
+            return CSV_ENOMEM;
+        }
+        (void)hipFree(sh->sig_raw);
+        sh->sig_raw = bigger; sh->sig_cap = new_cap;
         if ((rc = job_queue_front(ctx, job))) return rc;
     }
     const uint64_t n = h.n_sig, n_del = h.n_del;
@@ -1197,6 +1221,20 @@ int csvgpu_chr_job_end(csv_ctx *ctx, csv_job *job, csv_chr_result *res)
     return rc;
 }
 
+int csvgpu_chr_job_abort(csv_ctx *ctx, csv_job *job)
+{
+    if (!ctx || !job) return CSV_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    // whatever the job queued reads the shard's buffers: let it drain before the caller reuses or frees them
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->gate && ctx->gate->stream) (void)hipStreamSynchronize(ctx->gate->stream);
+    job_free(ctx, job);                                  // ctx->err keeps the failure that led here
+    return CSV_OK;
+}
+
+// Test hook (CPU-side error-path tests): the next n device allocations guarded by csv_test_fail_alloc() fail.
+void csvgpu_test_fail_next_alloc(int n) { csv::g_fail_alloc = n; }
+
 static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct, csv_chr_result *res,
                         csv_sig *host_sig, int32_t *host_labels, uint64_t capacity)
 {
@@ -1205,7 +1243,7 @@ static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t
     csv_job *job = csvgpu_chr_job_begin(ctx, sh, min_oplen, min_mapq, min_pts_pct);
     if (!job) return ctx->err.find("hipMalloc") != std::string::npos ? CSV_ENOMEM : CSV_EHIP;
     const int rc = csvgpu_chr_job_cluster(ctx, job, eps, host_sig, host_labels, capacity);
-    if (rc) { job_free(ctx, job); return rc; }
+    if (rc) { csvgpu_chr_job_abort(ctx, job); return rc; }
     return csvgpu_chr_job_end(ctx, job, res);
 }
 

@@ -114,7 +114,7 @@ void CNVCaller::runViterbi(const CHMM &hmm, const std::vector<SNPData> &data, st
     }
 }
 
-void CNVCaller::runCIGARCopyNumberPrediction(const std::string &chr, std::vector<SVCall> &sv_candidates, const CHMM &hmm, double mean_chr_cov,
+size_t CNVCaller::runCIGARCopyNumberPrediction(const std::string &chr, std::vector<SVCall> &sv_candidates, const CHMM &hmm, double mean_chr_cov,
                                              csv_shard *shard, const SNPSource &snps) const
 {
     std::vector<size_t> idx;
@@ -128,7 +128,7 @@ void CNVCaller::runCIGARCopyNumberPrediction(const std::string &chr, std::vector
         if ((c.end - c.start) < min_cnv_length) continue;               // :315
         idx.push_back(k); regions.emplace_back(c.start, c.end);
     }
-    if (idx.empty()) return;
+    if (idx.empty()) return 0;
     std::vector<SNPData> data;
     querySNPRegions(regions, shard, mean_chr_cov, snps, data);
     std::vector<std::pair<std::vector<int>, double>> pred;
@@ -159,6 +159,7 @@ void CNVCaller::runCIGARCopyNumberPrediction(const std::string &chr, std::vector
             sv_call.cn_state = max_state;
         }
     }
+    return idx.size();
 }
 
 void CNVCaller::runCopyNumberPredictions(const std::string &chr, const CHMM &hmm, const std::vector<std::pair<uint32_t, uint32_t>> &regions,

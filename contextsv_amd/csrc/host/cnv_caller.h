@@ -63,8 +63,8 @@ public:
     // runViterbi for many SNPData at once (one Viterbi launch)
     void runViterbi(const CHMM &hmm, const std::vector<SNPData> &data, std::vector<std::pair<std::vector<int>, double>> &predictions) const;
 
-    // cnv_caller.cpp:290-387 — updates sv_candidates in place
-    void runCIGARCopyNumberPrediction(const std::string &chr, std::vector<SVCall> &sv_candidates, const CHMM &hmm, double mean_chr_cov,
+    // cnv_caller.cpp:290-387 — updates sv_candidates in place; returns the number of candidates that went through the HMM
+    size_t runCIGARCopyNumberPrediction(const std::string &chr, std::vector<SVCall> &sv_candidates, const CHMM &hmm, double mean_chr_cov,
                                       csv_shard *shard, const SNPSource &snps) const;
 
     // cnv_caller.cpp:166-287 for a batch of regions. With save_cnv_data the flanking half-length windows are queried too and

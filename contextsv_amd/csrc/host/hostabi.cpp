@@ -18,7 +18,9 @@
 #include "bam_io.h"
 #include "snp_io.h"
 #include "fast_inflate.h"
+#include "umap_order.h"
 #include <fstream>
+#include <memory>
 #include <algorithm>
 #include <vector>
 
@@ -121,10 +123,17 @@ int csvhost_sort_select_check(const uint32_t *keys, uint64_t n, uint64_t nth, in
 // ---- synthetic shards -------------------------------------------------------------------------
 struct csvhost_synth { SynthShard sh; };
 
+csvhost_synth *csvhost_synth_generate2(uint64_t seed, uint32_t chr_len, double depth, int tech, int threads, int with_seq, double sv_per_bp);
 csvhost_synth *csvhost_synth_generate(uint64_t seed, uint32_t chr_len, double depth, int tech, int threads, int with_seq)
+{
+    return csvhost_synth_generate2(seed, chr_len, depth, tech, threads, with_seq, 0.0);
+}
+// sv_per_bp <= 0: the default density (one truth SV per 120 kb)
+csvhost_synth *csvhost_synth_generate2(uint64_t seed, uint32_t chr_len, double depth, int tech, int threads, int with_seq, double sv_per_bp)
 {
     try {
         SynthParams p; p.seed = seed; p.chr_len = chr_len; p.depth = depth; p.tech = tech; p.threads = threads; p.with_seq = with_seq;
+        if (sv_per_bp > 0) p.sv_per_bp = sv_per_bp;
         csvhost_synth *h = new csvhost_synth();
         synth_generate(p, h->sh);
         return h;
@@ -136,6 +145,7 @@ void csvhost_synth_view(const csvhost_synth *h, csv_reads *out, uint32_t *depth_
     if (seq_off) *seq_off = h->sh.seq_off.empty() ? nullptr : h->sh.seq_off.data();
     if (seq) *seq = h->sh.seq.empty() ? nullptr : h->sh.seq.data();
 }
+const uint32_t *csvhost_synth_qname_ids(const csvhost_synth *h) { return h->sh.qname_id.data(); }
 void csvhost_synth_free(csvhost_synth *h) { delete h; }
 
 // ---- per-chromosome CIGAR path (SVCaller::processChromosome mirror) ---------------------------
@@ -168,6 +178,36 @@ int csvhost_process_resident_chromosome(csv_ctx *ctx, csv_shard *shard, const ui
             out[i] = p;
             if (alt_tag) alt_tag[i] = c.alt_allele == "<DEL>" ? 0 : (c.alt_allele == "<INS>" ? 1 : 2);
         }
+    })
+}
+
+// ALT strings only: SVCaller::toSVCall for n signatures ('\n'-joined into buf, at most cap bytes; returns the full length through *len).
+// Host only — the 50-bp insertion ALT is cut from the 4-bit sequences here (sv_caller.cpp:572-590, :607-625 of the reference).
+int csvhost_sig_alts(const csv_sig *sig, uint64_t n, const uint64_t *seq_off, const uint8_t *seq, char *buf, uint64_t cap, uint64_t *len)
+{
+    GUARD({
+        SeqStore ss; ss.seq_off = seq_off; ss.seq = seq;
+        std::string t;
+        for (uint64_t i = 0; i < n; i++) { t += SVCaller::toSVCall(sig[i], seq ? &ss : nullptr).alt_allele; t += '\n'; }
+        if (buf && cap) memcpy(buf, t.data(), (size_t)std::min<uint64_t>(cap, t.size()));
+        *len = t.size();
+    })
+}
+
+// processChromosome on a resident shard, returning "<start>\t<end>\t<ALT>\n" per merged call (the string fields the POD view drops)
+int csvhost_process_resident_chromosome_alts(csv_ctx *ctx, csv_shard *shard, const uint64_t *seq_off, const uint8_t *seq, double eps, double min_pts_pct,
+                                             char *buf, uint64_t cap, uint64_t *len)
+{
+    GUARD({
+        SVCaller caller(ctx);
+        SeqStore ss; ss.seq_off = seq_off; ss.seq = seq;
+        std::vector<SVCall> calls;
+        ChrStats cs;
+        caller.processResidentChromosome("chr", shard, seq ? &ss : nullptr, eps, min_pts_pct, calls, cs);
+        std::string t;
+        for (const SVCall &c : calls) t += std::to_string(c.start) + "\t" + std::to_string(c.end) + "\t" + c.alt_allele + "\n";
+        if (buf && cap) memcpy(buf, t.data(), (size_t)std::min<uint64_t>(cap, t.size()));
+        *len = t.size();
     })
 }
 
@@ -282,6 +322,41 @@ int csvhost_split_signatures(csv_ctx *ctx, uint64_t n, const int32_t *tid, const
             }
         }
         *n_out = k;
+    })
+}
+
+// Test hook for umap_order.h (CPU): keys = n names ('\n'-joined) inserted in order with operator[], then every key with
+// erase_mask[i] != 0 is erased. order_real = for every surviving node of a real std::unordered_map<std::string,int>, the index of
+// the key's first insertion, in iteration order; order_emu = the same from csvhost::UMapOrder. Returns the count through *n_out
+// (both have the same length when the emulation is right; the caller compares).
+int csvhost_umap_order_check(const char *names, uint64_t n, const uint8_t *erase_mask, int64_t *order_real, int64_t *order_emu, uint64_t *n_real, uint64_t *n_emu,
+                             uint64_t *buckets_real, uint64_t *buckets_emu)
+{
+    GUARD({
+        std::vector<std::string> keys;
+        keys.reserve(n);
+        const char *p = names;
+        for (uint64_t i = 0; i < n; i++) {
+            const char *e = strchr(p, '\n');
+            keys.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+            p = e ? e + 1 : p + strlen(p);
+        }
+        std::unordered_map<std::string, int> real;
+        csvhost::UMapOrder emu;
+        std::vector<int64_t> first;
+        for (uint64_t i = 0; i < n; i++) {
+            real.emplace(keys[i], (int)i);                 // keeps the first index, as the emulation's `first` does
+            real[keys[i]];                                 // (operator[] on an existing key: no structural change)
+            const uint64_t h = csvhost::std_string_hash(keys[i].data(), keys[i].size());
+            if (emu.find(h, [&](uint32_t nd) { return keys[(size_t)first[nd]] == keys[i]; }) < 0) { emu.insert_new(h); first.push_back((int64_t)i); }
+        }
+        *buckets_real = real.bucket_count(); *buckets_emu = emu.bucket_count();
+        std::vector<char> dead(n, 0);
+        for (uint64_t i = 0; i < n; i++) if (erase_mask && erase_mask[i]) { real.erase(keys[i]); }
+        uint64_t a = 0, b = 0;
+        for (const auto &kv : real) order_real[a++] = kv.second;
+        emu.for_each([&](uint32_t nd) { if (real.count(keys[(size_t)first[nd]])) order_emu[b++] = first[nd]; });
+        *n_real = a; *n_emu = b;
     })
 }
 
@@ -404,6 +479,139 @@ int csvhost_run(csv_ctx *ctx, int n_contigs, const uint64_t *read_off, const uin
             }
         }
         *n_out = k;
+    })
+}
+
+// ---- a staged genome: contigs resident in HBM + the host arrays of the host-side passes (SVCaller::runResident) -----------
+struct csvhost_genome {
+    struct Contig {
+        std::string name;
+        int32_t global_tid = 0;
+        csv_ctx *ctx = nullptr;                 // the context the shard was uploaded with (frees it)
+        csv_shard *shard = nullptr;
+        uint32_t depth_len = 0;
+        uint64_t n_reads = 0, n_cigar = 0;
+        std::vector<int32_t> pos; std::vector<uint16_t> flag; std::vector<uint8_t> mapq;
+        std::vector<uint64_t> qhash, name_id;
+        SNPTable snps;
+    };
+    std::vector<std::unique_ptr<Contig>> contigs;
+    ~csvhost_genome() { for (auto &c : contigs) if (c->shard) csvgpu_shard_free(c->ctx, c->shard); }
+};
+
+csvhost_genome *csvhost_genome_create(void) { return new csvhost_genome(); }
+void csvhost_genome_free(csvhost_genome *g) { delete g; }
+
+// Stage one contig: upload the records (the shard stays resident), keep pos / flag / mapq and the query-name hash + identity of
+// every record on the host. Record i's query name is "r<global_tid>_<qname_id[i]>" (what the synthetic BAM writer calls it), so a
+// contig hashes the same whichever rank or lane it lands on (name_style 0: "r<id>", the naming of csvhost_run). SNPs: snp_pos / snp_baf (n_snp, sorted; no population frequency).
+int csvhost_genome_add(csvhost_genome *g, csv_ctx *ctx, const char *name, int32_t global_tid, const csv_reads *reads, uint32_t depth_len,
+                       const uint32_t *qname_id, int name_style /* 0: "r<id>" (names shared across contigs), 1: "r<tid>_<id>" */,
+                       const uint32_t *snp_pos, const double *snp_baf, const double *snp_pfb /* nullable: 0.0 */, const uint8_t *snp_has_pfb /* nullable: none */,
+                       uint64_t n_snp)
+{
+    GUARD({
+        std::unique_ptr<csvhost_genome::Contig> c(new csvhost_genome::Contig());
+        c->name = name; c->global_tid = global_tid; c->ctx = ctx; c->depth_len = depth_len;
+        c->n_reads = reads->n_reads; c->n_cigar = reads->n_cigar;
+        c->shard = csvgpu_shard_upload(ctx, reads, depth_len);
+        if (!c->shard) throw std::runtime_error(std::string("genome_add: ") + csvgpu_last_error(ctx));
+        const uint64_t n = reads->n_reads;
+        c->pos.assign(reads->pos, reads->pos + n); c->flag.assign(reads->flag, reads->flag + n); c->mapq.assign(reads->mapq, reads->mapq + n);
+        if (qname_id) {
+            c->qhash.resize(n); c->name_id.resize(n);
+            char buf[48];
+            const int pre = name_style ? snprintf(buf, sizeof buf, "r%d_", (int)global_tid) : snprintf(buf, sizeof buf, "r");
+            for (uint64_t i = 0; i < n; i++) {
+                const int len = pre + snprintf(buf + pre, sizeof buf - (size_t)pre, "%u", qname_id[i]);
+                c->qhash[i] = csvhost::std_string_hash(buf, (size_t)len);
+                c->name_id[i] = (name_style ? ((uint64_t)(uint32_t)global_tid << 32) : 0) | qname_id[i];
+            }
+        }
+        if (n_snp) {
+            c->snps.pos.assign(snp_pos, snp_pos + n_snp); c->snps.baf.assign(snp_baf, snp_baf + n_snp);
+            if (snp_pfb) c->snps.pfb.assign(snp_pfb, snp_pfb + n_snp); else c->snps.pfb.assign(n_snp, 0.0);
+            if (snp_has_pfb) c->snps.has_pfb.assign(snp_has_pfb, snp_has_pfb + n_snp); else c->snps.has_pfb.assign(n_snp, 0);
+        }
+        g->contigs.push_back(std::move(c));
+    })
+}
+
+// the same from a generated shard (+ generated SNPs when with_snps)
+int csvhost_genome_add_synth(csvhost_genome *g, csv_ctx *ctx, const char *name, int32_t global_tid, const csvhost_synth *syn, uint64_t snp_seed, int with_snps)
+{
+    const SynthShard &sh = syn->sh;
+    std::vector<uint32_t> sp; std::vector<double> sb;
+    if (with_snps) synth_snps(snp_seed, sh.depth_len - 1, sp, sb);
+    const csv_reads r = sh.view();
+    return csvhost_genome_add(g, ctx, name, global_tid, &r, sh.depth_len, sh.qname_id.data(), 1, sp.data(), sb.data(), nullptr, nullptr, sp.size());
+}
+
+struct csvhost_stage_times {
+    double ms_cigar, ms_cigar_cn, ms_split_fetch, ms_split, ms_split_cn, ms_merge_split, ms_merge_final, ms_vcf, ms_total;
+    uint64_t n_reads, n_signatures, n_cigar_calls, n_cigar_cn_regions, n_split_calls, n_final_calls;
+};
+
+uint64_t csvhost_genome_n_contigs(const csvhost_genome *g) { return g->contigs.size(); }
+void csvhost_genome_contig_info(const csvhost_genome *g, uint64_t i, uint64_t *n_reads, uint64_t *n_cigar, uint32_t *depth_len, int32_t *global_tid, csv_shard **shard)
+{
+    const auto &c = *g->contigs[i];
+    if (n_reads) *n_reads = c.n_reads;
+    if (n_cigar) *n_cigar = c.n_cigar;
+    if (depth_len) *depth_len = c.depth_len;
+    if (global_tid) *global_tid = c.global_tid;
+    if (shard) *shard = c.shard;
+}
+
+// One step: SVCaller::runResident over every staged contig. passes: bit 0 split-read pass, bit 1 CIGAR copy-number pass, bit 2 the two
+// final merges. Calls come back grouped by contig in staging order with the contig's GLOBAL tid in out_tid; stats[i] per contig.
+int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *const *lane_ctxs, const csv_hmm *hmm, double eps, double min_pts_pct,
+                       int sample_size, uint32_t min_cnv, int passes, int host_threads, csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out,
+                       csvhost_stage_times *times, csvhost_chr_stats *stats)
+{
+    GUARD({
+        std::vector<ResidentContig> rc(g->contigs.size());
+        for (size_t i = 0; i < rc.size(); i++) {
+            auto &c = *g->contigs[i];
+            rc[i].name = c.name; rc[i].shard = c.shard; rc[i].depth_len = c.depth_len; rc[i].snps = &c.snps;
+            rc[i].split.n = c.n_reads; rc[i].split.pos = c.pos.data(); rc[i].split.flag = c.flag.data(); rc[i].split.mapq = c.mapq.data();
+            if (!c.qhash.empty()) { rc[i].split.qhash = c.qhash.data(); rc[i].split.name_id = c.name_id.data(); }
+        }
+        RunParams P; P.dbscan_epsilon = eps; P.dbscan_min_pts_pct = min_pts_pct; P.sample_size = sample_size; P.min_cnv_length = min_cnv;
+        P.split_svs = (passes & 1) != 0; P.cigar_cn = (passes & 2) != 0; P.merge_split_svs = P.merge_final_svs = (passes & 4) != 0;
+        P.host_threads = host_threads;
+        std::vector<csv_ctx *> lanes(lane_ctxs, lane_ctxs + (n_lanes > 0 ? n_lanes : 0));
+        SVCaller caller(ctx);
+        std::unordered_map<std::string, std::vector<SVCall>> calls;
+        std::vector<ChrStats> cs;
+        RunStageTimes T;
+        caller.runResident(rc, lanes, chmm_from_pod(hmm), P, calls, &cs, &T);
+        uint64_t k = 0;
+        for (size_t i = 0; i < rc.size(); i++) {
+            const std::vector<SVCall> &v = calls[rc[i].name];
+            for (const SVCall &c : v) {
+                if (k < cap) {
+                    csvhost_call p;
+                    p.start = c.start; p.end = c.end; p.sv_type = (int32_t)c.sv_type; p.cluster_size = c.cluster_size; p.hmm_likelihood = c.hmm_likelihood;
+                    p.id = -1; p.aln_flags = (uint32_t)c.aln_type.to_ulong(); p.genotype = (int32_t)c.genotype; p.cn_state = c.cn_state; p.aln_offset = c.aln_offset;
+                    out[k] = p; out_tid[k] = g->contigs[i]->global_tid;
+                }
+                k++;
+            }
+            if (stats) {
+                csvhost_chr_stats &st = stats[i];
+                st.n_signatures = cs[i].n_signatures; st.n_del = cs[i].n_del; st.n_ins = cs[i].n_ins; st.depth_sum = cs[i].depth_sum;
+                st.depth_nonzero = cs[i].depth_nonzero; st.min_pts = cs[i].dbscan_min_pts; st.mean_cov = cs[i].mean_chr_cov;
+                st.ms_device = cs[i].ms_device; st.ms_host_merge = cs[i].ms_host_merge; st.n_calls = v.size();
+            }
+        }
+        *n_out = k;
+        if (times) {
+            times->ms_cigar = T.ms_cigar; times->ms_cigar_cn = T.ms_cigar_cn; times->ms_split_fetch = T.ms_split_fetch; times->ms_split = T.ms_split;
+            times->ms_split_cn = T.ms_split_cn; times->ms_merge_split = T.ms_merge_split; times->ms_merge_final = T.ms_merge_final; times->ms_vcf = T.ms_vcf;
+            times->ms_total = T.ms_total; times->n_reads = T.n_reads; times->n_signatures = T.n_signatures; times->n_cigar_calls = T.n_cigar_calls;
+            times->n_cigar_cn_regions = T.n_cigar_cn_regions; times->n_split_calls = T.n_split_calls; times->n_final_calls = T.n_final_calls;
+        }
     })
 }
 
@@ -577,7 +785,7 @@ int csvhost_bam_write(const char *path, const char *text, int n_ref, const char 
 }
 
 // The synthetic shard as a coordinate-sorted BAM + BAI on one contig ("stage inputs ... as a real BGZF BAM + BAI").
-// Query names are r<index>; sequences are written when the shard has them, else l_seq = 0 ("*").
+// Query names are r<read id> (a primary and its supplementary record share one); sequences are written when the shard has them, else l_seq = 0 ("*").
 int csvhost_synth_write_bam(const csvhost_synth *h, const char *path, const char *chr_name, int level, int threads, uint64_t *bam_bytes)
 {
     GUARD({
@@ -596,7 +804,7 @@ int csvhost_synth_write_bam(const csvhost_synth *h, const char *path, const char
             const uint32_t nc = (uint32_t)(sh.cigar_off[i + 1] - sh.cigar_off[i]);
             int32_t l_seq = 0;
             if (have_seq) for (uint32_t k = 0; k < nc; k++) if ((0x3C1A7u >> ((cg[k] & 15) << 1)) & 1) l_seq += (int32_t)(cg[k] >> 4);   // query-consuming ops
-            w.add(0, sh.pos[i], sh.mapq[i], sh.flag[i], "r" + std::to_string(i), cg, nc, have_seq ? sh.seq.data() + sh.seq_off[i] : nullptr, l_seq, nullptr);
+            w.add(0, sh.pos[i], sh.mapq[i], sh.flag[i], "r" + std::to_string(sh.qname_id[i]), cg, nc, have_seq ? sh.seq.data() + sh.seq_off[i] : nullptr, l_seq, nullptr);
         }
         if (!w.close()) throw std::runtime_error(w.error());
         if (bam_bytes) { bgzf::MappedFile f; std::string e; *bam_bytes = f.open(path, &e) ? f.size() : 0; }
@@ -629,7 +837,7 @@ int csvhost_bam_writer_append_synth(csvhost_bam_writer *h, const csvhost_synth *
         const SynthShard &sh = syn->sh;
         for (size_t i = 0; i < sh.pos.size(); i++) {
             if (i && sh.pos[i] < sh.pos[i - 1]) throw std::runtime_error("synthetic shard is not coordinate-sorted");
-            h->w.add(tid, sh.pos[i], sh.mapq[i], sh.flag[i], "r" + std::to_string(tid) + "_" + std::to_string(i), sh.cigar.data() + sh.cigar_off[i],
+            h->w.add(tid, sh.pos[i], sh.mapq[i], sh.flag[i], "r" + std::to_string(tid) + "_" + std::to_string(sh.qname_id[i]), sh.cigar.data() + sh.cigar_off[i],
                      (uint32_t)(sh.cigar_off[i + 1] - sh.cigar_off[i]), nullptr, 0, nullptr);
         }
     })

@@ -1,13 +1,17 @@
 #include "split_caller.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <exception>
 #include <memory>
-#include <set>
-#include <unordered_set>
+#include <stdexcept>
+#include <thread>
 
 #include "dbscan.h"
 #include "log.h"
+#include "umap_order.h"
 
 namespace {
 
@@ -23,11 +27,11 @@ struct SuppAlignment { int tid, start, end, query_start, query_end; bool strand;
 // recursive insert / findOverlaps recurse once per node. The same shape is built here in O(n log n): the tree a sequence of
 // BST insertions produces is the Cartesian tree of the keys (start, insertion index) with the insertion index as heap priority.
 struct IntervalTree {
-    struct Node { PrimaryAlignment region; const std::string *qname; int max_end; int32_t left, right; };
+    struct Node { PrimaryAlignment region; uint32_t member; int max_end; int32_t left, right; };
     std::vector<Node> nodes;                     // in insertion order
     int32_t root = -1;
 
-    void add(const PrimaryAlignment &r, const std::string *q) { nodes.push_back(Node{r, q, r.end, -1, -1}); }
+    void add(const PrimaryAlignment &r, uint32_t member) { nodes.push_back(Node{r, member, r.end, -1, -1}); }
 
     void build()
     {
@@ -55,14 +59,14 @@ struct IntervalTree {
     }
 
     // findOverlaps: node, then left (if it can overlap), then right, on an explicit stack
-    void overlaps(const PrimaryAlignment &q, std::vector<const std::string *> &out, std::vector<int32_t> &stack) const
+    void overlaps(const PrimaryAlignment &q, std::vector<uint32_t> &out, std::vector<int32_t> &stack) const
     {
         stack.clear();
         if (root >= 0) stack.push_back(root);
         while (!stack.empty()) {
             const Node &n = nodes[(size_t)stack.back()];
             stack.pop_back();
-            if (q.start <= n.region.end && q.end >= n.region.start) out.push_back(n.qname);
+            if (q.start <= n.region.end && q.end >= n.region.start) out.push_back(n.member);
             // The reference always descends to the right (:961). Subtrees that cannot hold an overlap contribute nothing, so skipping
             // them keeps the result and its order: right descendants all start at or after this node, and max_end bounds every end.
             if (n.right >= 0 && n.region.start <= q.end && nodes[(size_t)n.right].max_end >= q.start) stack.push_back(n.right);
@@ -93,84 +97,154 @@ struct Group {
     std::vector<int> sets[6];   // primary starts, primary ends, supp starts, supp ends, read distances, ref distances
 };
 
+
+// ---- query-name equality across contigs (names themselves, or run-wide dictionary ids) ---------------------------------
+bool same_name(const SplitContig &a, uint64_t i, const SplitContig &b, uint64_t j)
+{
+    if (a.name_bytes && b.name_bytes) {
+        const uint64_t la = a.name_off[i + 1] - a.name_off[i], lb = b.name_off[j + 1] - b.name_off[j];
+        return la == lb && memcmp(a.name_bytes + a.name_off[i], b.name_bytes + b.name_off[j], (size_t)la) == 0;
+    }
+    return a.name_id[i] == b.name_id[j];
+}
+
+// a supplementary record in file order, found again by its name's hash (supp_map, sv_caller.cpp:162-165)
+struct SuppRef { uint64_t hash; uint64_t ord; uint32_t contig; uint32_t rec; };   // ord: position in the file
+
+// What one contig's thread keeps between the phases.
+struct ContigWork {
+    const SplitContig *in = nullptr;
+    csvhost::UMapOrder order;                      // chr_primary_map's node list, all primaries
+    std::vector<PrimaryAlignment> prim;            // by node
+    std::vector<uint32_t> first_rec;               // by node: the record that created the key
+    std::vector<SuppRef> supps;                    // this contig's supplementary records, file order
+    // survivors (primaries with a supplementary record) in the map's iteration order
+    std::vector<PrimaryAlignment> member;
+    std::vector<std::vector<SuppAlignment>> member_supps;
+    std::vector<Group> groups;
+    size_t set_base = 0;                           // first of this contig's point sets in the genome-wide batch
+    size_t n_primary = 0;
+    std::vector<SVCall> calls;
+};
+
+template <class F>
+void parallel_over(size_t n, int threads, F f)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t T = threads > 0 ? (size_t)threads : (size_t)(hw ? hw : 1);
+    T = std::max<size_t>(1, std::min(T, n));
+    if (T == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::exception_ptr> errs(T);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            try { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); } catch (...) { errs[t] = std::current_exception(); }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : errs) if (e) std::rethrow_exception(e);
+}
+
 }  // namespace
 
-void findSplitSVSignatures(const std::vector<SplitRecord> &records, const std::vector<std::string> &qnames,
-                           const std::vector<std::string> &target_names, const SplitParams &params,
+void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::vector<std::string> &target_names, const SplitParams &params,
                            std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
 {
-    // ---- collect primaries and supplementaries (sv_caller.cpp:137-172) ------------------------------------------------
-    std::unordered_map<int, std::unordered_map<std::string, PrimaryAlignment>> primary_map;
-    std::unordered_map<std::string, std::vector<SuppAlignment>> supp_map;
-    std::unordered_set<std::string> supp_qnames;
-    for (size_t i = 0; i < records.size(); i++) {
-        const SplitRecord &r = records[i];
-        if ((r.flag & (FLAG_SECONDARY | FLAG_UNMAP | FLAG_DUP | FLAG_QCFAIL)) || r.mapq < params.min_mapq) continue;
-        const bool strand = !(r.flag & FLAG_REVERSE);
-        if (!(r.flag & FLAG_SUPP)) {
-            primary_map[r.tid][qnames[i]] = PrimaryAlignment{r.pos + 1, r.ref_end, r.q_start, r.q_end, strand, 0};   // later record wins
-        } else {
-            supp_map[qnames[i]].push_back(SuppAlignment{r.tid, r.pos + 1, r.ref_end, r.q_start, r.q_end, strand});
-            supp_qnames.insert(qnames[i]);
-        }
-    }
-    // ---- drop primaries that have no supplementary record (:183-202) ---------------------------------------------------
-    {
-        std::unordered_map<int, std::unordered_set<std::string>> to_remove;
-        for (auto &chr_primary : primary_map)
-            for (const auto &entry : chr_primary.second)
-                if (supp_qnames.find(entry.first) == supp_qnames.end()) to_remove[chr_primary.first].insert(entry.first);
-        int total_removed = 0;
-        for (auto &chr_primary : primary_map) {
-            total_removed += (int)to_remove[chr_primary.first].size();
-            for (const auto &q : to_remove[chr_primary.first]) chr_primary.second.erase(q);
-        }
-        printMessage("Removed " + std::to_string(total_removed) + " primary alignments without supplementary alignments");
+    for (const SplitContig &c : contigs)
+        if (c.n && (!c.qhash || (!c.name_id && !(c.name_bytes && c.name_off)))) throw std::runtime_error("findSplitSVSignatures: a contig without query-name hashes or identities");
+    // larger contigs first: the wall time of a parallel phase is the largest contig's
+    std::vector<size_t> by_size(contigs.size());
+    for (size_t i = 0; i < by_size.size(); i++) by_size[i] = i;
+    std::sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return contigs[a].n != contigs[b].n ? contigs[a].n > contigs[b].n : a < b; });
+    // one work item per tid (a tid split over several blocks is one map in the reference: blocks of a tid are chained in order)
+    std::vector<ContigWork> work(contigs.size());
+    for (size_t c = 0; c < contigs.size(); c++) {
+        work[c].in = &contigs[c];
+        for (size_t d = 0; d < c; d++) if (contigs[d].tid == contigs[c].tid) throw std::runtime_error("findSplitSVSignatures: two blocks with the same tid");
     }
 
-    for (const auto &chr_primary : primary_map) {
-        const int primary_tid = chr_primary.first;
-        const std::string chr_name = target_names.at((size_t)primary_tid);
-        const std::unordered_map<std::string, PrimaryAlignment> &chr_primary_map = chr_primary.second;
-        printMessage("Processing chromosome " + chr_name + " with " + std::to_string(chr_primary_map.size()) + " primary alignments");
+    // ---- phase 1: collect primaries (into the replayed map) and supplementaries (sv_caller.cpp:137-172), per contig ------------
+    parallel_over(contigs.size(), params.threads, [&](size_t k) {
+        ContigWork &W = work[by_size[k]];
+        const SplitContig &C = *W.in;
+        W.order.reserve((size_t)C.n);
+        for (uint64_t i = 0; i < C.n; i++) {
+            const uint16_t flag = C.flag[i];
+            if ((flag & (FLAG_SECONDARY | FLAG_UNMAP | FLAG_DUP | FLAG_QCFAIL)) || C.mapq[i] < params.min_mapq) continue;
+            if (flag & FLAG_SUPP) { W.supps.push_back(SuppRef{C.qhash[i], C.file_idx ? C.file_idx[i] : (((uint64_t)by_size[k] << 40) | i), (uint32_t)by_size[k], (uint32_t)i}); continue; }
+            const PrimaryAlignment p{C.pos[i] + 1, C.ref_end[i], C.q_start[i], C.q_end[i], !(flag & FLAG_REVERSE), 0};
+            const int64_t node = W.order.find(C.qhash[i], [&](uint32_t nd) { return same_name(C, W.first_rec[nd], C, i); });
+            if (node >= 0) { W.prim[(size_t)node] = p; continue; }                       // operator[]: a later record of the name wins (:152)
+            W.order.insert_new(C.qhash[i]);
+            W.prim.push_back(p);
+            W.first_rec.push_back((uint32_t)i);
+        }
+        W.n_primary = W.prim.size();
+    });
 
-        // ---- overlap groups (:215-238): direct overlaps of the first unprocessed read in hash order, not transitive ----
+    // ---- supp_map: every supplementary record of the run by name, file order within a name (:162-165) ---------------------------
+    std::vector<SuppRef> supp_index;
+    for (const ContigWork &W : work) supp_index.insert(supp_index.end(), W.supps.begin(), W.supps.end());
+    std::sort(supp_index.begin(), supp_index.end(), [](const SuppRef &a, const SuppRef &b) { return a.hash != b.hash ? a.hash < b.hash : a.ord < b.ord; });
+
+    // ---- phase 2: survivors in iteration order, interval tree, overlap groups, the six point sets (:183-347), per contig ---------
+    std::atomic<long> total_removed{0};
+    parallel_over(contigs.size(), params.threads, [&](size_t k) {
+        ContigWork &W = work[by_size[k]];
+        const SplitContig &C = *W.in;
+        const int primary_tid = C.tid;
+        W.order.for_each([&](uint32_t node) {
+            const uint64_t h = C.qhash[W.first_rec[node]];
+            auto lo = std::lower_bound(supp_index.begin(), supp_index.end(), h, [](const SuppRef &a, uint64_t x) { return a.hash < x; });
+            std::vector<SuppAlignment> mine;
+            for (; lo != supp_index.end() && lo->hash == h; ++lo) {
+                const SplitContig &S = *work[lo->contig].in;
+                if (!same_name(C, W.first_rec[node], S, lo->rec)) continue;              // equal hash, different name
+                const uint32_t r = lo->rec;
+                mine.push_back(SuppAlignment{S.tid, S.pos[r] + 1, S.ref_end[r], S.q_start[r], S.q_end[r], !(S.flag[r] & FLAG_REVERSE)});
+            }
+            if (mine.empty()) return;                                                   // erased: no supplementary record (:183-202)
+            W.member.push_back(W.prim[node]);
+            W.member_supps.push_back(std::move(mine));
+        });
+        total_removed += (long)(W.n_primary - W.member.size());
+        // the map's storage is not needed any more
+        W.order = csvhost::UMapOrder(); W.prim = {}; W.first_rec = {};
+
+        // overlap groups (:215-238): direct overlaps of the first unprocessed read in iteration order, not transitive
         IntervalTree tree;
-        tree.nodes.reserve(chr_primary_map.size());
-        for (const auto &entry : chr_primary_map) tree.add(entry.second, &entry.first);
+        tree.nodes.reserve(W.member.size());
+        for (size_t m = 0; m < W.member.size(); m++) tree.add(W.member[m], (uint32_t)m);
         tree.build();
-        std::vector<std::vector<const std::string *>> primary_clusters;
+        std::vector<std::vector<uint32_t>> primary_clusters;
         {
-            std::set<std::string> processed;
+            std::vector<char> processed(W.member.size(), 0);
             std::vector<int32_t> walk;
-            for (const auto &entry : chr_primary_map) {
-                if (processed.find(entry.first) != processed.end()) continue;
-                std::vector<const std::string *> group;
-                tree.overlaps(entry.second, group, walk);
-                for (const std::string *q : group) processed.insert(*q);
+            for (size_t m = 0; m < W.member.size(); m++) {
+                if (processed[m]) continue;
+                std::vector<uint32_t> group;
+                tree.overlaps(W.member[m], group, walk);
+                for (uint32_t q : group) processed[q] = 1;
                 if (group.size() > 1) primary_clusters.push_back(std::move(group));
             }
         }
-
-        // ---- the six point sets of every group (:248-347), then ONE batched DBSCAN1D launch -----------------------------
-        std::vector<Group> groups(primary_clusters.size());
+        W.groups.assign(primary_clusters.size(), Group());
         for (size_t g = 0; g < primary_clusters.size(); g++) {
-            Group &G = groups[g];
+            Group &G = W.groups[g];
             const auto &members = primary_clusters[g];
             int n_opposite = 0;
-            for (const std::string *q : members) {
-                const PrimaryAlignment &p = chr_primary_map.at(*q);
-                const std::vector<SuppAlignment> &supps = supp_map[*q];
+            for (uint32_t q : members) {
+                const PrimaryAlignment &p = W.member[q];
                 bool opposite = false;
-                for (const SuppAlignment &s : supps) if (s.tid == primary_tid && s.strand != p.strand) opposite = true;
+                for (const SuppAlignment &s : W.member_supps[q]) if (s.tid == primary_tid && s.strand != p.strand) opposite = true;
                 n_opposite += opposite;
                 G.sets[0].push_back(p.start);
                 G.sets[1].push_back(p.end);
             }
             G.inversion = (double)n_opposite / (double)(int)members.size() > 0.5;                   // :265
-            for (const std::string *q : members) {
-                const PrimaryAlignment &p = chr_primary_map.at(*q);
-                for (const SuppAlignment &s : supp_map.at(*q)) {
+            for (uint32_t q : members) {
+                const PrimaryAlignment &p = W.member[q];
+                for (const SuppAlignment &s : W.member_supps[q]) {
                     if (s.tid != primary_tid) continue;                                                // translocations: ignored (:352-354)
                     G.sets[2].push_back(s.start);
                     G.sets[3].push_back(s.end);
@@ -184,18 +258,27 @@ void findSplitSVSignatures(const std::vector<SplitRecord> &records, const std::v
                 }
             }
         }
-        std::vector<std::vector<int>> flat_sets, flat_labels;
-        flat_sets.reserve(groups.size() * 6);
-        for (Group &G : groups) for (int k = 0; k < 6; k++) flat_sets.push_back(G.sets[k]);
-        if (!flat_sets.empty()) DBSCAN1D::fitBatch(flat_sets, params.eps, params.min_pts, flat_labels);
+    });
+    printMessage("Removed " + std::to_string(total_removed.load()) + " primary alignments without supplementary alignments");
 
-        // ---- medians, SPLITDIST1 candidates, SPLIT dummies (:283-486) ----------------------------------------------------
-        std::vector<SVCall> chr_sv_calls;
+    // ---- the six DBSCAN1D(100, 5) fits of every group of every contig: ONE batched launch (:270-372) ------------------------------
+    std::vector<std::vector<int>> flat_sets, flat_labels;
+    for (ContigWork &W : work) {
+        W.set_base = flat_sets.size();
+        for (Group &G : W.groups) for (int s = 0; s < 6; s++) flat_sets.push_back(G.sets[s]);
+    }
+    if (!flat_sets.empty()) DBSCAN1D::fitBatch(flat_sets, params.eps, params.min_pts, flat_labels);
+
+    // ---- phase 3: medians, SPLITDIST1 candidates, SPLIT dummies (:283-486), per contig --------------------------------------------
+    parallel_over(contigs.size(), params.threads, [&](size_t k) {
+        ContigWork &W = work[by_size[k]];
+        if (W.n_primary == 0) return;                        // no entry in primary_map for this tid
+        std::vector<SVCall> &chr_sv_calls = W.calls;
         chr_sv_calls.reserve(1000);
-        for (size_t g = 0; g < groups.size(); g++) {
-            Group &G = groups[g];
+        for (size_t g = 0; g < W.groups.size(); g++) {
+            Group &G = W.groups[g];
             std::vector<int> cl[6];
-            for (int k = 0; k < 6; k++) cl[k] = largest_cluster(G.sets[k], flat_labels[g * 6 + k]);
+            for (int s = 0; s < 6; s++) cl[s] = largest_cluster(G.sets[s], flat_labels[W.set_base + g * 6 + (size_t)s]);
             std::vector<int> &p_start = cl[0], &p_end = cl[1], &s_start = cl[2], &s_end = cl[3], &read_d = cl[4], &ref_d = cl[5];
             if (p_start.empty() && p_end.empty()) continue;                                          // :291-293
             if (s_start.empty() && s_end.empty() && read_d.empty() && ref_d.empty()) continue;        // :375-377
@@ -257,7 +340,45 @@ void findSplitSVSignatures(const std::vector<SplitRecord> &records, const std::v
             return a.start < b.start || (a.start == b.start && a.end < b.end);
         });
         mergeDuplicateSVs(chr_sv_calls);
-        sv_calls[chr_name] = std::move(chr_sv_calls);
-        printMessage(chr_name + ": Found " + std::to_string(sv_calls[chr_name].size()) + " SV candidates");
+    });
+    for (ContigWork &W : work) {
+        if (W.n_primary == 0) continue;
+        const std::string chr_name = target_names.at((size_t)W.in->tid);
+        printMessage("Processing chromosome " + chr_name + " with " + std::to_string(W.member.size()) + " primary alignments");
+        printMessage(chr_name + ": Found " + std::to_string(W.calls.size()) + " SV candidates");
+        sv_calls[chr_name] = std::move(W.calls);
     }
+}
+
+void findSplitSVSignatures(const std::vector<SplitRecord> &records, const std::vector<std::string> &qnames,
+                           const std::vector<std::string> &target_names, const SplitParams &params,
+                           std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
+{
+    // regroup by tid (file order kept inside a tid; tids in order of first appearance, which is file order for a sorted BAM)
+    struct Block { int32_t tid; std::vector<int32_t> pos, ref_end, q_start, q_end; std::vector<uint16_t> flag; std::vector<uint8_t> mapq;
+                   std::vector<uint64_t> qhash, name_off, file_idx; std::string names; };
+    std::vector<std::unique_ptr<Block>> blocks;
+    std::unordered_map<int32_t, size_t> at;
+    for (size_t i = 0; i < records.size(); i++) {
+        const SplitRecord &r = records[i];
+        auto it = at.find(r.tid);
+        if (it == at.end()) { it = at.emplace(r.tid, blocks.size()).first; blocks.emplace_back(new Block()); blocks.back()->tid = r.tid; blocks.back()->name_off.push_back(0); }
+        Block &b = *blocks[it->second];
+        b.pos.push_back(r.pos); b.ref_end.push_back(r.ref_end); b.q_start.push_back(r.q_start); b.q_end.push_back(r.q_end);
+        b.flag.push_back(r.flag); b.mapq.push_back(r.mapq);
+        b.qhash.push_back(csvhost::std_string_hash(qnames[i].data(), qnames[i].size()));
+        b.names += qnames[i];
+        b.file_idx.push_back(i);
+        b.name_off.push_back(b.names.size());
+    }
+    std::vector<SplitContig> contigs;
+    for (auto &bp : blocks) {
+        Block &b = *bp;
+        SplitContig c;
+        c.tid = b.tid; c.n = b.pos.size();
+        c.pos = b.pos.data(); c.flag = b.flag.data(); c.mapq = b.mapq.data(); c.ref_end = b.ref_end.data(); c.q_start = b.q_start.data(); c.q_end = b.q_end.data();
+        c.qhash = b.qhash.data(); c.name_bytes = b.names.data(); c.name_off = b.name_off.data(); c.file_idx = b.file_idx.data();
+        contigs.push_back(c);
+    }
+    findSplitSVSignatures(contigs, target_names, params, sv_calls);
 }

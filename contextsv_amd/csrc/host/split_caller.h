@@ -4,9 +4,10 @@
 // What moved to the GPU: the per-record CIGAR walk of the reference's third BAM pass (getAlignmentReadPositions +
 // bam_endpos, :152, :162) — the scan kernel already produced ref_end / q_start / q_end for every record — and the six
 // DBSCAN1D(100, 5) fits per overlap group (:270-372), which are collected for ALL groups of a chromosome and solved by
-// one batched launch (DBSCAN1D::fitBatch -> csvgpu_dbscan_1d). What stays here, with the reference's own containers
-// because their iteration order is observable (SURVEY §7 hard part 2): the qname-keyed unordered_maps, the
-// (unbalanced) interval tree built in hash order, the overlap groups, the medians and votes.
+// one batched launch for the whole genome (DBSCAN1D::fitBatch -> csvgpu_dbscan_1d). What stays here: the order-defining
+// steps (SURVEY §7 hard part 2) — the iteration order of the reference's qname-keyed unordered_map, replayed exactly by
+// umap_order.h instead of building 6e5 string-keyed nodes per chromosome; the (unbalanced) interval tree that order builds; the
+// overlap groups, medians and votes — one host thread per contig, contigs being independent.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -32,9 +33,33 @@ struct SplitParams {
     int min_pts = 5;
     int min_length = 2000;    // :243
     int max_length = 1000000; // :244
+    int threads = 0;          // host threads over contigs (0: one per contig, at most the hardware's); the result does not depend on it
 };
 
-// records[i] belongs to qnames[i]; target_names[tid] is the contig name. Fills sv_calls[contig] like the reference.
+// The records of one contig (one tid), struct of arrays, file order — what a decoded shard holds on the host plus the scan
+// kernel's intervals. Query names are needed for two things only: their std::hash<std::string> value (qhash: it fixes where the
+// reference's unordered_map puts a read, see umap_order.h) and equality. Equality comes from the names themselves (name_bytes /
+// name_off) or from run-wide dictionary ids (name_id: equal id <=> equal name) — at least one of the two must be given.
+struct SplitContig {
+    int32_t tid = 0;
+    uint64_t n = 0;
+    const int32_t *pos = nullptr;
+    const uint16_t *flag = nullptr;
+    const uint8_t *mapq = nullptr;
+    const int32_t *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr;
+    const uint64_t *qhash = nullptr;
+    const uint64_t *name_id = nullptr;
+    const char *name_bytes = nullptr;
+    const uint64_t *name_off = nullptr;      // [n + 1]
+    const uint64_t *file_idx = nullptr;      // optional: position of each record in the file (default: contigs in the order given, records in array order)
+};
+
+// Fills sv_calls[target_names[tid]] for every contig that has primary alignments, like the reference. Contigs must be given in
+// file order (or carry file_idx): a read's supplementary records are visited in file order.
+void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::vector<std::string> &target_names, const SplitParams &params,
+                           std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
+
+// Same, from records in file order (any mix of tids) and their names as strings.
 void findSplitSVSignatures(const std::vector<SplitRecord> &records, const std::vector<std::string> &qnames,
                            const std::vector<std::string> &target_names, const SplitParams &params,
                            std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);

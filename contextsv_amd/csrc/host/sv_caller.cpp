@@ -10,9 +10,12 @@
 #include <stdexcept>
 #include <atomic>
 
+#include <memory>
+
 #include "dbscan.h"
 #include "log.h"
 #include "sort_select.h"
+#include "umap_order.h"
 
 namespace {
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -176,7 +179,14 @@ void SVCaller::processResidentChromosome(const std::string &chr, csv_shard *shar
 void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *> &shards, const SeqStore *seq, double eps, double pct,
                                                    std::vector<std::vector<SVCall>> &calls, std::vector<ChrStats> &stats)
 {
+    processResidentChromosomesPipelined(shards, seq ? std::vector<const SeqStore *>(shards.size(), seq) : std::vector<const SeqStore *>(), eps, pct, calls, stats);
+}
+
+void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *> &shards, const std::vector<const SeqStore *> &seqs, double eps, double pct,
+                                                   std::vector<std::vector<SVCall>> &calls, std::vector<ChrStats> &stats)
+{
     const size_t n = shards.size();
+    if (!seqs.empty() && seqs.size() != n) throw std::invalid_argument("processResidentChromosomesPipelined: one SeqStore per shard, or none");
     calls.assign(n, {});
     stats.assign(n, ChrStats());
     // The representative choice of one chromosome (~0.5 ms for chr22: a sequential selection over the noise bucket) takes about as
@@ -195,7 +205,7 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
             try {
                 for (size_t i = w; i < n; i += kMergers) {
                     { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return ready[i] || failed; }); if (failed) return; }
-                    hostMerge("shard" + std::to_string(i), slot[i % kSlots], seq, calls[i], stats[i]);
+                    hostMerge("shard" + std::to_string(i), slot[i % kSlots], seqs.empty() ? nullptr : seqs[i], calls[i], stats[i]);
                     { std::lock_guard<std::mutex> l(mu); merged[i] = 1; }
                     cv.notify_all();
                 }
@@ -232,12 +242,16 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
             csv_job *job = ahead;
             ahead = nullptr;
             int rc = csvgpu_chr_job_cluster(ctx, job, eps, out.sig, out.lab, out.cap);
-            if (rc) { csvgpu_chr_job_end(ctx, job, nullptr); check(ctx, rc, "processChromosome"); }
+            if (rc) { csvgpu_chr_job_abort(ctx, job); check(ctx, rc, "processChromosome"); }      // abort keeps the failure's own message
             // the next shard's scan + depth pass go into the queue now, behind this shard's clustering and copies: the device
             // does not wait for the host's turn-around (result wait, hand-over to a merge thread, next call)
             if (i + 1 < n) {
                 ahead = csvgpu_chr_job_begin(ctx, shards[i + 1], (uint32_t)min_oplen, (uint8_t)min_mapq, pct);
-                if (!ahead) { csvgpu_chr_job_end(ctx, job, nullptr); throw std::runtime_error(std::string("processChromosome: ") + csvgpu_last_error(ctx)); }
+                if (!ahead) {
+                    const std::string why = csvgpu_last_error(ctx);
+                    csvgpu_chr_job_abort(ctx, job);
+                    throw std::runtime_error("processChromosome: " + why);
+                }
             }
             csv_chr_result res;
             rc = csvgpu_chr_job_end(ctx, job, &res);
@@ -254,9 +268,9 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
             { std::lock_guard<std::mutex> l(mu); ready[i] = 1; }
             cv.notify_all();
         }
-        if (ahead) { csvgpu_chr_job_end(ctx, ahead, nullptr); ahead = nullptr; }      // only after a merge-thread failure cut the loop short
+        if (ahead) { csvgpu_chr_job_abort(ctx, ahead); ahead = nullptr; }      // only after a merge-thread failure cut the loop short
     } catch (...) {
-        if (ahead) csvgpu_chr_job_end(ctx, ahead, nullptr);
+        if (ahead) csvgpu_chr_job_abort(ctx, ahead);
         stop_workers();
         throw;
     }
@@ -275,7 +289,8 @@ void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqSto
         threads.emplace_back([&, l] {
             try {
                 SVCaller caller(lanes[l].ctx);
-                caller.processResidentChromosomesPipelined(lanes[l].shards, seq, eps, pct, calls[l], stats[l]);
+                if (!lanes[l].seqs.empty()) caller.processResidentChromosomesPipelined(lanes[l].shards, lanes[l].seqs, eps, pct, calls[l], stats[l]);
+                else caller.processResidentChromosomesPipelined(lanes[l].shards, seq, eps, pct, calls[l], stats[l]);
             } catch (...) { errs[l] = std::current_exception(); }
         });
     }
@@ -325,95 +340,194 @@ void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
                    std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls)
 {
     csvhost::set_context(ctx);
-    const EmptySnps no_snps;
     // what outlives a contig's host arrays: its shard (reads, depth map, alignment intervals in HBM), its statistics, its SNP
-    // source, and the 28 bytes + query name per record that the split-read pass groups by
-    std::vector<std::string> names;
-    std::vector<csv_shard *> shards;
+    // source, and per record the 7 bytes + query name (hash + bytes) that the split-read pass groups by
+    struct Kept {
+        std::vector<int32_t> pos; std::vector<uint16_t> flag; std::vector<uint8_t> mapq;
+        std::vector<uint64_t> qhash, name_off; std::string names;
+    };
+    std::vector<std::unique_ptr<Kept>> kept;
+    std::vector<ResidentContig> contigs;
     std::vector<ChrStats> stats;
-    std::vector<uint32_t> depth_lens;
-    std::vector<const SNPSource *> snps;
-    std::vector<SplitRecord> records;
-    std::vector<std::string> qnames;
-    std::unordered_map<std::string, size_t> index_of;
-    auto free_all = [&] { for (csv_shard *s : shards) if (s) csvgpu_shard_free(ctx, s); };
+    auto free_all = [&] { for (ResidentContig &c : contigs) if (c.shard) csvgpu_shard_free(ctx, c.shard); };
     try {
         // depth pass + CIGAR pass + CIGAR merge (sv_caller.cpp:794-863); the reference pre-seeds the map with every contig
         ChromosomeInput c;
         while (source.next(c)) {
-            const size_t i = names.size();
-            names.push_back(c.name);
-            shards.push_back(nullptr);
+            const size_t i = contigs.size();
+            contigs.emplace_back();
             stats.emplace_back();
-            snps.push_back(c.snps);
-            depth_lens.push_back(c.depth_len);
-            index_of[c.name] = i;
+            kept.emplace_back(new Kept());
+            contigs[i].name = c.name; contigs[i].depth_len = c.depth_len; contigs[i].snps = c.snps;
+            contigs[i].seq = nullptr;                                 // the sequences are only valid until the next contig: ALT strings are cut now
+            contigs[i].split.tid = (int32_t)i;
             std::vector<SVCall> calls;
-            if (P.cigar_svs) processChromosome(c.name, c.reads, c.seq, c.depth_len, P.dbscan_epsilon, P.dbscan_min_pts_pct, calls, stats[i], &shards[i]);
+            if (P.cigar_svs) processChromosome(c.name, c.reads, c.seq, c.depth_len, P.dbscan_epsilon, P.dbscan_min_pts_pct, calls, stats[i], &contigs[i].shard);
             whole_genome_sv_calls[c.name] = std::move(calls);
-            if (P.split_svs && c.qnames && shards[i]) {                                 // inputs of the split-read pass (:133-175)
+            if (P.split_svs && c.qnames && contigs[i].shard) {                          // inputs of the split-read pass (:133-175)
                 const uint64_t n = c.reads.n_reads;
-                std::vector<int32_t> ref_end(n), q_start(n), q_end(n);
-                check(ctx, csvgpu_aln_intervals_resident(ctx, shards[i], ref_end.data(), q_start.data(), q_end.data()), "alignment intervals");
-                records.reserve(records.size() + n);
+                Kept &K = *kept[i];
+                K.pos.assign(c.reads.pos, c.reads.pos + n); K.flag.assign(c.reads.flag, c.reads.flag + n); K.mapq.assign(c.reads.mapq, c.reads.mapq + n);
+                K.qhash.resize(n); K.name_off.resize(n + 1);
+                size_t bytes = 0;
+                for (uint64_t r = 0; r < n; r++) bytes += (*c.qnames)[r].size();
+                K.names.reserve(bytes);
                 for (uint64_t r = 0; r < n; r++) {
-                    records.push_back(SplitRecord{(int32_t)i, c.reads.pos[r], c.reads.flag[r], c.reads.mapq[r], ref_end[r], q_start[r], q_end[r]});
-                    qnames.push_back((*c.qnames)[r]);
+                    const std::string &q = (*c.qnames)[r];
+                    K.qhash[r] = csvhost::std_string_hash(q.data(), q.size());
+                    K.name_off[r] = K.names.size();
+                    K.names += q;
                 }
+                K.name_off[n] = K.names.size();
+                SplitContig &sc = contigs[i].split;
+                sc.n = n; sc.pos = K.pos.data(); sc.flag = K.flag.data(); sc.mapq = K.mapq.data();
+                sc.qhash = K.qhash.data(); sc.name_bytes = K.names.data(); sc.name_off = K.name_off.data();
             }
         }
-        CNVCaller cnv(ctx);
-        cnv.sample_size = P.sample_size; cnv.min_cnv_length = P.min_cnv_length;
-        if (P.save_cnv && !P.vcf.output_dir.empty()) {                                 // main.cpp:109-118
-            cnv.save_cnv_data = true;
-            cnv.cnv_output_file = P.vcf.output_dir + "/CNVCalls.json";
-            std::remove(cnv.cnv_output_file.c_str());
-            printMessage("Saving CNV data to: " + cnv.cnv_output_file);
-        }
-        if (P.cigar_svs && P.cigar_cn) {                                               // :865-881
-            printMessage("Running copy number predictions on CIGAR SVs...");
-            for (auto &entry : whole_genome_sv_calls) {
-                if (entry.second.empty()) continue;
-                const size_t i = index_of.at(entry.first);
-                cnv.runCIGARCopyNumberPrediction(entry.first, entry.second, hmm, stats[i].mean_chr_cov, shards[i],
-                                                 snps[i] ? *snps[i] : (const SNPSource &)no_snps);
-            }
-        }
-        if (P.split_svs) {                                                             // :885-917
-            std::unordered_map<std::string, std::vector<SVCall>> split_calls;
-            SplitParams sp; sp.min_mapq = min_mapq;
-            findSplitSVSignatures(records, qnames, names, sp, split_calls);
-            for (auto &entry : split_calls) {
-                if (entry.second.empty()) continue;
-                const size_t i = index_of.at(entry.first);
-                cnv.runSplitReadCopyNumberPredictions(entry.first, entry.second, hmm, stats[i].mean_chr_cov, shards[i],
-                                                      snps[i] ? *snps[i] : (const SNPSource &)no_snps, depth_lens[i]);
-            }
-            if (P.merge_split_svs) for (auto &entry : split_calls) mergeSVs(entry.second, 0.1, 2, true);
-            for (auto &entry : split_calls) {
-                std::vector<SVCall> &dst = whole_genome_sv_calls[entry.first];
-                dst.insert(dst.end(), entry.second.begin(), entry.second.end());
-            }
-        }
-        if (P.merge_final_svs) for (auto &entry : whole_genome_sv_calls) mergeSVs(entry.second, 0.1, 2, true);   // :919-927
-        if (cnv.save_cnv_data) CNVCaller::closeJSON(cnv.cnv_output_file);                                       // :929-931
-        uint32_t total = 0;
-        for (const auto &entry : whole_genome_sv_calls) {
-            total += getSVCount(entry.second);
-            printMessage("Total SVs detected for " + entry.first + ": " + std::to_string(getSVCount(entry.second)));
-        }
-        printMessage("Total SVs detected: " + std::to_string(total));
-        if (P.ref_genome && !P.vcf.output_dir.empty()) {                               // :943-945
-            printMessage("Saving SVs to VCF...");
-            ShardDepthSource depth(ctx);
-            for (size_t i = 0; i < names.size(); i++) if (shards[i]) depth.add(names[i], shards[i]);
-            saveToVCF(whole_genome_sv_calls, P.vcf, *P.ref_genome, depth);
-        }
+        RunStageTimes T;
+        finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T);
     } catch (...) {
         free_all();
         throw;
     }
     free_all();
+}
+
+void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const std::vector<csv_ctx *> &lane_ctxs, const CHMM &hmm, const RunParams &P,
+                           std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, std::vector<ChrStats> *stats_out, RunStageTimes *times)
+{
+    csvhost::set_context(ctx);
+    const double t_begin = now_ms();
+    RunStageTimes T;
+    std::vector<ResidentContig> contigs = contigs_in;
+    const size_t n = contigs.size();
+    std::vector<ChrStats> stats(n);
+    std::vector<std::vector<SVCall>> per(n);
+    if (P.cigar_svs && n) {
+        // contigs over the lanes: longest processing time first by read count, every lane works down its list
+        const size_t L = std::max<size_t>(1, lane_ctxs.size());
+        std::vector<Lane> lanes(L);
+        std::vector<std::vector<size_t>> which(L);
+        for (size_t l = 0; l < L; l++) lanes[l].ctx = lane_ctxs.empty() ? ctx : lane_ctxs[l];
+        std::vector<size_t> order(n);
+        for (size_t i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return contigs[a].split.n != contigs[b].split.n ? contigs[a].split.n > contigs[b].split.n : contigs[a].depth_len != contigs[b].depth_len ? contigs[a].depth_len > contigs[b].depth_len : a < b; });
+        std::vector<double> load(L, 0.0);
+        for (size_t i : order) {
+            size_t l = 0;
+            for (size_t k = 1; k < L; k++) if (load[k] < load[l]) l = k;
+            lanes[l].shards.push_back(contigs[i].shard);
+            lanes[l].seqs.push_back(contigs[i].seq);
+            which[l].push_back(i);
+            load[l] += (double)std::max<uint64_t>(contigs[i].split.n, contigs[i].depth_len / 400);
+        }
+        std::vector<std::vector<std::vector<SVCall>>> lane_calls;
+        std::vector<std::vector<ChrStats>> lane_stats;
+        if (L == 1) {
+            lane_calls.resize(1); lane_stats.resize(1);
+            SVCaller one(lanes[0].ctx);
+            one.min_mapq = min_mapq; one.min_oplen = min_oplen;
+            one.processResidentChromosomesPipelined(lanes[0].shards, lanes[0].seqs, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls[0], lane_stats[0]);
+        } else {
+            processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats);
+        }
+        for (size_t l = 0; l < L; l++)
+            for (size_t k = 0; k < which[l].size(); k++) { per[which[l][k]] = std::move(lane_calls[l][k]); stats[which[l][k]] = lane_stats[l][k]; }
+    }
+    for (size_t i = 0; i < n; i++) {                                   // the map is filled in contig order, as run() does
+        T.n_signatures += stats[i].n_signatures; T.n_cigar_calls += per[i].size(); T.n_reads += contigs[i].split.n;
+        whole_genome_sv_calls[contigs[i].name] = std::move(per[i]);
+    }
+    T.ms_cigar = now_ms() - t_begin;
+    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T);
+    T.ms_total = now_ms() - t_begin;
+    if (stats_out) *stats_out = stats;
+    if (times) *times = T;
+}
+
+void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
+                         std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T)
+{
+    const EmptySnps no_snps;
+    std::unordered_map<std::string, size_t> index_of;
+    std::vector<std::string> names;
+    for (size_t i = 0; i < contigs.size(); i++) { index_of[contigs[i].name] = i; names.push_back(contigs[i].name); }
+    CNVCaller cnv(ctx);
+    cnv.sample_size = P.sample_size; cnv.min_cnv_length = P.min_cnv_length;
+    if (P.save_cnv && !P.vcf.output_dir.empty()) {                                 // main.cpp:109-118
+        cnv.save_cnv_data = true;
+        cnv.cnv_output_file = P.vcf.output_dir + "/CNVCalls.json";
+        std::remove(cnv.cnv_output_file.c_str());
+        printMessage("Saving CNV data to: " + cnv.cnv_output_file);
+    }
+    double t0 = now_ms();
+    if (P.cigar_svs && P.cigar_cn) {                                               // :865-881
+        printMessage("Running copy number predictions on CIGAR SVs...");
+        for (auto &entry : whole_genome_sv_calls) {
+            if (entry.second.empty()) continue;
+            const size_t i = index_of.at(entry.first);
+            T.n_cigar_cn_regions += cnv.runCIGARCopyNumberPrediction(entry.first, entry.second, hmm, stats[i].mean_chr_cov, contigs[i].shard,
+                                                                     contigs[i].snps ? *contigs[i].snps : (const SNPSource &)no_snps);
+        }
+    }
+    T.ms_cigar_cn = now_ms() - t0;
+    if (P.split_svs) {                                                             // :885-917
+        t0 = now_ms();
+        // the scan kernel's per-read intervals (the reference's third BAM pass, :137-172) come back from the shards
+        std::vector<std::vector<int32_t>> iv(contigs.size() * 3);
+        std::vector<SplitContig> blocks;
+        for (size_t i = 0; i < contigs.size(); i++) {
+            ResidentContig &c = contigs[i];
+            if (!c.split.qhash || !c.shard || !c.split.n) continue;
+            const uint64_t n = c.split.n;
+            for (int k = 0; k < 3; k++) iv[i * 3 + (size_t)k].resize(n);
+            check(ctx, csvgpu_aln_intervals_resident(ctx, c.shard, iv[i * 3].data(), iv[i * 3 + 1].data(), iv[i * 3 + 2].data()), "alignment intervals");
+            c.split.tid = (int32_t)i;
+            c.split.ref_end = iv[i * 3].data(); c.split.q_start = iv[i * 3 + 1].data(); c.split.q_end = iv[i * 3 + 2].data();
+            blocks.push_back(c.split);
+        }
+        T.ms_split_fetch = now_ms() - t0;
+        t0 = now_ms();
+        std::unordered_map<std::string, std::vector<SVCall>> split_calls;
+        SplitParams sp; sp.min_mapq = min_mapq; sp.threads = P.host_threads;
+        findSplitSVSignatures(blocks, names, sp, split_calls);
+        T.ms_split = now_ms() - t0;
+        t0 = now_ms();
+        for (auto &entry : split_calls) {
+            if (entry.second.empty()) continue;
+            const size_t i = index_of.at(entry.first);
+            cnv.runSplitReadCopyNumberPredictions(entry.first, entry.second, hmm, stats[i].mean_chr_cov, contigs[i].shard,
+                                                  contigs[i].snps ? *contigs[i].snps : (const SNPSource &)no_snps, contigs[i].depth_len);
+        }
+        T.ms_split_cn = now_ms() - t0;
+        t0 = now_ms();
+        if (P.merge_split_svs) for (auto &entry : split_calls) mergeSVs(entry.second, 0.1, 2, true);
+        for (auto &entry : split_calls) {
+            T.n_split_calls += entry.second.size();
+            std::vector<SVCall> &dst = whole_genome_sv_calls[entry.first];
+            dst.insert(dst.end(), entry.second.begin(), entry.second.end());
+        }
+        T.ms_merge_split = now_ms() - t0;
+    }
+    t0 = now_ms();
+    if (P.merge_final_svs) for (auto &entry : whole_genome_sv_calls) mergeSVs(entry.second, 0.1, 2, true);   // :919-927
+    T.ms_merge_final = now_ms() - t0;
+    if (cnv.save_cnv_data) CNVCaller::closeJSON(cnv.cnv_output_file);                                       // :929-931
+    uint32_t total = 0;
+    for (const auto &entry : whole_genome_sv_calls) {
+        total += getSVCount(entry.second);
+        printMessage("Total SVs detected for " + entry.first + ": " + std::to_string(getSVCount(entry.second)));
+    }
+    T.n_final_calls = total;
+    printMessage("Total SVs detected: " + std::to_string(total));
+    if (P.ref_genome && !P.vcf.output_dir.empty()) {                               // :943-945
+        t0 = now_ms();
+        printMessage("Saving SVs to VCF...");
+        ShardDepthSource depth(ctx);
+        for (const ResidentContig &c : contigs) if (c.shard) depth.add(c.name, c.shard);
+        saveToVCF(whole_genome_sv_calls, P.vcf, *P.ref_genome, depth);
+        T.ms_vcf = now_ms() - t0;
+    }
 }
 
 // ---- the run fed from a BAM file ----------------------------------------------------------------------------------

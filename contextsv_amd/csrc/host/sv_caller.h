@@ -50,12 +50,40 @@ struct ContigSource {
     virtual bool next(ChromosomeInput &out) = 0;
 };
 
+// A contig whose records are already resident in HBM (csvgpu_shard_upload / csvgpu_shard_wrap_dev) together with the small
+// per-record host arrays the host-side passes read: the decoded, staged form of one chromosome. `split` carries pos / flag / mapq
+// and the query names (hash + identity, see split_caller.h); its ref_end / q_start / q_end are filled by the run from the scan
+// kernel's per-read outputs. split.qhash == nullptr: the contig takes no part in the split-read pass.
+struct ResidentContig {
+    std::string name;
+    csv_shard *shard = nullptr;
+    uint32_t depth_len = 0;                 // contig length + 1
+    const SeqStore *seq = nullptr;          // for the 50-bp insertion ALT strings (may be null: N's)
+    const SNPSource *snps = nullptr;        // nullptr: no SNPs
+    SplitContig split;
+};
+
+// Wall time of each pass of one run (the order of SVCaller::run, sv_caller.cpp:804-945) and what went through it.
+struct RunStageTimes {
+    double ms_cigar = 0;        // depth + CIGAR scan + ordering + DBSCAN + mergeSVs, all contigs
+    double ms_cigar_cn = 0;     // runCIGARCopyNumberPrediction, all contigs
+    double ms_split_fetch = 0;  // alignment intervals device -> host
+    double ms_split = 0;        // findSplitSVSignatures
+    double ms_split_cn = 0;     // runSplitReadCopyNumberPredictions
+    double ms_merge_split = 0;  // mergeSVs(0.1, 2, true) on the split calls + concatenation
+    double ms_merge_final = 0;  // mergeSVs(0.1, 2, true) on the union
+    double ms_vcf = 0;
+    double ms_total = 0;
+    uint64_t n_reads = 0, n_signatures = 0, n_cigar_calls = 0, n_cigar_cn_regions = 0, n_split_calls = 0, n_final_calls = 0;
+};
+
 struct RunParams {
     double dbscan_epsilon = 0.1;            // --eps          (input_data.cpp:18-37)
     double dbscan_min_pts_pct = 0.1;        // --min-pts-pct
     int sample_size = 20;                   // --sample-size
     uint32_t min_cnv_length = 2000;         // --min-cnv
     bool cigar_svs = true, cigar_cn = true, split_svs = true, merge_split_svs = true, merge_final_svs = true;   // sv_caller.cpp:749-753
+    int host_threads = 0;                   // host threads of the split-read and copy-number passes over contigs / regions (0: the hardware's); results do not depend on it
     bool save_cnv = false;                  // --save-cnv: <vcf.output_dir>/CNVCalls.json (main.cpp:109-118, sv_caller.cpp:929-931)
     std::string snp_vcf;                    // --snp: the sample's SNP VCF (runBam; "" = no SNPs, every window gets the dummy observation)
     std::string pfb_table;                  // --pfb: "<chr>=<gnomAD VCF>" table
@@ -95,10 +123,14 @@ public:
     void processResidentChromosomesPipelined(const std::vector<csv_shard *> &shards, const SeqStore *seq, double dbscan_epsilon,
                                              double dbscan_min_pts_pct, std::vector<std::vector<SVCall>> &calls,
                                              std::vector<ChrStats> &stats);
+    // (seqs[i] belongs to shards[i]; an empty vector = no sequences)
+    void processResidentChromosomesPipelined(const std::vector<csv_shard *> &shards, const std::vector<const SeqStore *> &seqs, double dbscan_epsilon,
+                                             double dbscan_min_pts_pct, std::vector<std::vector<SVCall>> &calls,
+                                             std::vector<ChrStats> &stats);
 
     // Several chromosomes in flight on one GPU: every lane is a context of its own (own stream; attach one csv_gate to all of them so
     // that their scan + depth pairs run back to back on the gate's stream) and runs processResidentChromosomesPipelined on its shards in its own pair of threads.
-    struct Lane { csv_ctx *ctx; std::vector<csv_shard *> shards; };
+    struct Lane { csv_ctx *ctx; std::vector<csv_shard *> shards; std::vector<const SeqStore *> seqs; /* per shard, or empty */ };
     static void processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double dbscan_epsilon, double dbscan_min_pts_pct,
                                      std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats);
 
@@ -111,6 +143,14 @@ public:
              std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls);
     void run(ContigSource &source, const CHMM &hmm, const RunParams &params,
              std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls);
+
+    // The same run over contigs that are already resident in HBM — one *step* of the whole-genome benchmark: the CIGAR pass of all
+    // contigs through `lanes` (contexts of this GPU that share a gate; the contigs are spread over them by read count, longest
+    // processing time first; one lane = this caller's own context when `lanes` is empty), then the passes of run() in the
+    // reference's order. Nothing is uploaded or freed; the contigs can be run again.
+    void runResident(const std::vector<ResidentContig> &contigs, const std::vector<csv_ctx *> &lanes, const CHMM &hmm, const RunParams &params,
+                     std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, std::vector<ChrStats> *stats = nullptr,
+                     RunStageTimes *times = nullptr);
 
     // The same run fed from a coordinate-sorted, indexed BAM (reference: SVCaller::run(const InputData&) opening the file three
     // times per contig, sv_caller.cpp:747-863): each contig is decoded once by BamReader (threads = inflate threads) while the
@@ -127,6 +167,10 @@ public:
 
 private:
     csv_ctx *ctx;
+    // everything of run() behind the CIGAR pass: CIGAR copy-number predictions, split-read signatures + their predictions, the two
+    // final merges, the VCF (sv_caller.cpp:865-945). stats[i] belongs to contigs[i].
+    void finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
+                   std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T);
     struct DeviceOut {                       // what the device chain of one shard hands to the host merge: page-locked result buffers
         csv_ctx *ctx = nullptr;
         csv_sig *sig = nullptr;

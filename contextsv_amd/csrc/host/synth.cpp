@@ -28,6 +28,7 @@ struct ReadRec {
     int32_t pos; uint16_t flag; uint8_t mapq;
     uint64_t c0, c1;     // range in the thread-local cigar vector
     uint32_t thread;
+    uint32_t qid;        // the read this record belongs to (a primary and its supplementary share it)
 };
 
 struct ThreadOut {
@@ -105,7 +106,7 @@ void synth_generate(const SynthParams &p, SynthShard &out)
             const uint8_t mq = unif(g) < 0.05 ? (uint8_t)(g() % 20) : 60;
             const double clip_p = ont ? 0.3 : 0.1;
 
-            ReadRec rec; rec.pos = (int32_t)start; rec.flag = flag; rec.mapq = mq; rec.thread = (uint32_t)t; rec.c0 = o.cigar.size();
+            ReadRec rec; rec.pos = (int32_t)start; rec.flag = flag; rec.mapq = mq; rec.thread = (uint32_t)t; rec.qid = (uint32_t)r; rec.c0 = o.cigar.size();
             if (unif(g) < clip_p) o.cigar.push_back(cg(S, 10 + (uint32_t)(g() % 291)));
             uint32_t ref = start, end = start + len;
             size_t k = std::lower_bound(svs.begin(), svs.end(), ref, [](const TruthSV &a, uint32_t x) { return a.pos < x; }) - svs.begin();
@@ -129,7 +130,7 @@ void synth_generate(const SynthParams &p, SynthShard &out)
                         if (rest >= 200) {
                             o.cigar.push_back(cg(S, rest));
                             rec.c1 = o.cigar.size(); o.recs.push_back(rec);
-                            ReadRec sup; sup.thread = (uint32_t)t; sup.flag = (uint16_t)(flag | 0x800); sup.mapq = mq;
+                            ReadRec sup; sup.thread = (uint32_t)t; sup.qid = (uint32_t)r; sup.flag = (uint16_t)(flag | 0x800); sup.mapq = mq;
                             const uint32_t jump = v.type == 0 ? vlen : (v.type == 2 ? vlen : 0);
                             sup.pos = (int32_t)std::min<uint64_t>((uint64_t)ref + jump, p.chr_len > 300 ? p.chr_len - 300 : 0);
                             sup.c0 = o.cigar.size();
@@ -172,11 +173,11 @@ void synth_generate(const SynthParams &p, SynthShard &out)
     for (auto &o : outs) all.insert(all.end(), o.recs.begin(), o.recs.end());
     std::stable_sort(all.begin(), all.end(), [](const ReadRec &a, const ReadRec &b) { return a.pos < b.pos; });
     out.pos.resize(tot); out.flag.resize(tot); out.mapq.resize(tot); out.tid.assign(tot, 0);
-    out.cigar_off.resize(tot + 1); out.cigar.resize(tot_c);
+    out.cigar_off.resize(tot + 1); out.cigar.resize(tot_c); out.qname_id.resize(tot);
     uint64_t w = 0;
     for (size_t i = 0; i < tot; i++) {
         const ReadRec &r = all[i];
-        out.pos[i] = r.pos; out.flag[i] = r.flag; out.mapq[i] = r.mapq; out.cigar_off[i] = w;
+        out.pos[i] = r.pos; out.flag[i] = r.flag; out.mapq[i] = r.mapq; out.cigar_off[i] = w; out.qname_id[i] = r.qid;
         const uint32_t *src = outs[r.thread].cigar.data();
         std::copy(src + r.c0, src + r.c1, out.cigar.begin() + w);
         w += r.c1 - r.c0;
@@ -204,5 +205,17 @@ void synth_generate(const SynthParams &p, SynthShard &out)
             uint8_t *d = out.seq.data() + out.seq_off[i];
             for (uint32_t q = 0; q < (qlen[i] + 1) / 2; q++) { const uint64_t x = g(); d[q] = (uint8_t)((codes[x & 7] << 4) | codes[(x >> 3) & 7]); }
         }
+    }
+}
+
+// SNPs of a synthetic sample: about one per kilobase, heterozygous (BAF 0.5 +- 0.05) two times out of three, else
+// homozygous (BAF 1.0); no population frequency (a run without --pfb: the reference's map then default-constructs 0.0).
+void synth_snps(uint64_t seed, uint32_t chr_len, std::vector<uint32_t> &pos, std::vector<double> &baf)
+{
+    std::mt19937_64 g(mix(seed ^ 0x534E5053ull));
+    pos.clear(); baf.clear();
+    for (uint64_t p = 500 + g() % 1000; p < chr_len; p += 500 + g() % 1000) {
+        pos.push_back((uint32_t)p);
+        baf.push_back(unif(g) < 2.0 / 3.0 ? 0.45 + 0.1 * unif(g) : 1.0);
     }
 }

@@ -26,9 +26,11 @@ struct SynthShard {
     std::vector<uint32_t> cigar;
     std::vector<uint64_t> seq_off;
     std::vector<uint8_t>  seq;
+    std::vector<uint32_t> qname_id;     // [n_reads] read identity: a primary and its supplementary record share it (query name "r<tid>_<id>")
     uint32_t depth_len = 0;
     uint64_t n_truth_sv = 0;
     csv_reads view() const;
 };
 
 void synth_generate(const SynthParams &p, SynthShard &out);
+void synth_snps(uint64_t seed, uint32_t chr_len, std::vector<uint32_t> &pos, std::vector<double> &baf);

@@ -27,6 +27,12 @@ class bam_stats(C.Structure):
                 ("ms_decode", C.c_double), ("ms_total", C.c_double)]
 
 
+class stage_times(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("ms_cigar", "ms_cigar_cn", "ms_split_fetch", "ms_split", "ms_split_cn", "ms_merge_split", "ms_merge_final",
+                                          "ms_vcf", "ms_total")] + \
+               [(k, C.c_uint64) for k in ("n_reads", "n_signatures", "n_cigar_calls", "n_cigar_cn_regions", "n_split_calls", "n_final_calls")]
+
+
 _P = C.c_void_p
 _hlib = None
 
@@ -113,6 +119,23 @@ def load() -> C.CDLL:
     lib.csvhost_bam_writer_open.argtypes = [C.c_char_p, C.c_int, C.c_char_p, _P, C.c_int, C.c_int]
     lib.csvhost_bam_writer_append_synth.argtypes = [_P, _P, C.c_int]
     lib.csvhost_bam_writer_close.argtypes = [_P]
+    lib.csvhost_umap_order_check.argtypes = [C.c_char_p, C.c_uint64, _P, _P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_uint64)]
+    lib.csvhost_synth_qname_ids.restype = _P
+    lib.csvhost_synth_qname_ids.argtypes = [_P]
+    lib.csvhost_genome_create.restype = _P
+    lib.csvhost_genome_free.argtypes = [_P]
+    lib.csvhost_genome_add.argtypes = [_P, _P, C.c_char_p, C.c_int32, C.POINTER(_lib.csv_reads), C.c_uint32, _P, C.c_int, _P, _P, _P, _P, C.c_uint64]
+    lib.csvhost_synth_generate2.restype = _P
+    lib.csvhost_synth_generate2.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.csvhost_genome_add_synth.argtypes = [_P, _P, C.c_char_p, C.c_int32, _P, C.c_uint64, C.c_int]
+    lib.csvhost_genome_n_contigs.restype = C.c_uint64
+    lib.csvhost_genome_n_contigs.argtypes = [_P]
+    lib.csvhost_genome_contig_info.argtypes = [_P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(_P)]
+    lib.csvhost_genome_run.argtypes = [_P, _P, C.c_int, _P, C.POINTER(_lib.csv_hmm), C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_int, _P, _P,
+                                       C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(stage_times), _P]
+    lib.csvhost_sig_alts.argtypes = [_P, C.c_uint64, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.csvhost_process_resident_chromosome_alts.argtypes = [_P, _P, _P, _P, C.c_double, C.c_double, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -174,9 +197,9 @@ def add_sv_calls_order(calls: np.ndarray) -> np.ndarray:
 class SynthShard:
     """A generated shard living in the host library's memory; `reads` are zero-copy numpy views."""
 
-    def __init__(self, seed: int, chr_len: int, depth: float, tech: int = 0, threads: int = 8, with_seq: bool = False):
+    def __init__(self, seed: int, chr_len: int, depth: float, tech: int = 0, threads: int = 8, with_seq: bool = False, sv_per_bp: float = 0.0):
         lib = load()
-        self.h = lib.csvhost_synth_generate(seed, chr_len, depth, tech, threads, int(with_seq))
+        self.h = lib.csvhost_synth_generate2(seed, chr_len, depth, tech, threads, int(with_seq), sv_per_bp)
         if not self.h:
             raise RuntimeError((lib.csvhost_last_error() or b"").decode())
         r = _lib.csv_reads()
@@ -200,6 +223,7 @@ class SynthShard:
         self.reads.cigar_off = view(r.cigar_off, n + 1, np.uint64)
         self.reads.cigar = view(r.cigar, m, np.uint32)
         self.seq_off_ptr, self.seq_ptr = so.value, sq.value
+        self.qname_id = view(lib.csvhost_synth_qname_ids(self.h), n, np.uint32)
 
     def write_bam(self, path: str, chr_name: str = "chr22", level: int = 1, threads: int = 8) -> int:
         """The shard as a coordinate-sorted BAM + BAI on one contig; returns the BAM's size in bytes."""
@@ -212,6 +236,103 @@ class SynthShard:
             self.reads = None
             load().csvhost_synth_free(self.h)
             self.h = None
+
+
+class Genome:
+    """A staged genome: contigs resident in HBM + the small host arrays of the host-side passes; run() = SVCaller::runResident
+    (one step of the whole-genome benchmark). Contigs are added through a Context (they may use different contexts of one GPU)."""
+
+    def __init__(self):
+        self.h = load().csvhost_genome_create()
+        self.names = []
+
+    def add(self, ctx: Context, name: str, global_tid: int, reads: Reads, depth_len: int, qname_id=None, snps=None, name_style: int = 0):
+        rs = reads.c_struct()
+        q = np.ascontiguousarray(qname_id, np.uint32) if qname_id is not None else None
+        sp = np.ascontiguousarray(snps["pos"], np.uint32) if snps is not None else np.zeros(0, np.uint32)
+        sb = np.ascontiguousarray(snps["baf"], np.float64) if snps is not None else np.zeros(0, np.float64)
+        sf = np.ascontiguousarray(snps["pfb"], np.float64) if snps is not None and "pfb" in snps else None
+        sh = np.ascontiguousarray(snps["has_pfb"], np.uint8) if snps is not None and "has_pfb" in snps else None
+        _check(load().csvhost_genome_add(self.h, ctx.h, name.encode(), global_tid, C.byref(rs), depth_len, q.ctypes.data if q is not None else None,
+                                         name_style, sp.ctypes.data, sb.ctypes.data, sf.ctypes.data if sf is not None else None,
+                                         sh.ctypes.data if sh is not None else None, len(sp)))
+        self.names.append(name)
+
+    def add_synth(self, ctx: Context, name: str, global_tid: int, syn: "SynthShard", snp_seed: int = 0, with_snps: bool = True):
+        _check(load().csvhost_genome_add_synth(self.h, ctx.h, name.encode(), global_tid, syn.h, snp_seed, int(with_snps)))
+        self.names.append(name)
+
+    def __len__(self):
+        return int(load().csvhost_genome_n_contigs(self.h))
+
+    def contig_info(self, i: int) -> dict:
+        nr, nc, dl, gt, sh = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_int32(0), _P()
+        load().csvhost_genome_contig_info(self.h, i, C.byref(nr), C.byref(nc), C.byref(dl), C.byref(gt), C.byref(sh))
+        return {"n_reads": nr.value, "n_cigar": nc.value, "depth_len": dl.value, "global_tid": gt.value, "shard": sh.value}
+
+    def run(self, ctx: Context, hmm, lanes=None, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True, cigar_cn=True, merges=True,
+            host_threads=0, capacity: int = 1 << 20):
+        """-> (calls[CALL_DTYPE], global tid per call, stage_times, per-contig chr_stats list)"""
+        n = len(self)
+        out = np.zeros(capacity, CALL_DTYPE)
+        tid = np.zeros(capacity, np.int32)
+        k = C.c_uint64(0)
+        st = stage_times()
+        cs = (chr_stats * max(n, 1))()
+        lanes = lanes or []
+        lp = (C.c_void_p * max(len(lanes), 1))(*[c.h for c in lanes])
+        _check(load().csvhost_genome_run(self.h, ctx.h, len(lanes), lp, C.byref(hmm), eps, min_pts_pct, sample_size, min_cnv,
+                                         int(split_svs) | (int(cigar_cn) << 1) | (int(merges) << 2), host_threads, out.ctypes.data, tid.ctypes.data, capacity,
+                                         C.byref(k), C.byref(st), cs))
+        if k.value > capacity:
+            raise RuntimeError("Genome.run: capacity too small")
+        return out[: k.value].copy(), tid[: k.value].copy(), st, list(cs)[:n]
+
+    def free(self):
+        if self.h:
+            load().csvhost_genome_free(self.h)
+            self.h = None
+
+
+def umap_order_check(keys, erase_mask=None):
+    """(order of a real std::unordered_map<std::string,int>, order from the replay in umap_order.h, bucket counts) — CPU only."""
+    n = len(keys)
+    blob = "\n".join(keys).encode()
+    a, b = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64)
+    na, nb, ba, bb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    em = np.ascontiguousarray(erase_mask, np.uint8) if erase_mask is not None else None
+    _check(load().csvhost_umap_order_check(blob, n, em.ctypes.data if em is not None else None, a.ctypes.data, b.ctypes.data, C.byref(na), C.byref(nb),
+                                           C.byref(ba), C.byref(bb)))
+    return a[: na.value].copy(), b[: nb.value].copy(), (ba.value, bb.value)
+
+
+def sig_alts(sig: np.ndarray, seq_off=None, seq=None):
+    """ALT string of every signature (SVCaller::toSVCall; host only). seq_off: uint64[n_reads + 1] byte offsets, seq: uint8 4-bit packed."""
+    sig = np.ascontiguousarray(sig, _lib.SIG_DTYPE)
+    so = np.ascontiguousarray(seq_off, np.uint64) if seq_off is not None else None
+    sq = np.ascontiguousarray(seq, np.uint8) if seq is not None else None
+    cap = 64 * len(sig) + 16
+    buf = C.create_string_buffer(cap)
+    ln = C.c_uint64(0)
+    _check(load().csvhost_sig_alts(sig.ctypes.data, len(sig), so.ctypes.data if so is not None else None, sq.ctypes.data if sq is not None else None,
+                                   buf, cap, C.byref(ln)))
+    return buf.raw[: ln.value].decode().split("\n")[:-1]
+
+
+def process_resident_chromosome_alts(ctx: Context, shard: Shard, eps: float, min_pts_pct: float, seq_off=None, seq=None):
+    """processChromosome on a resident shard -> [(start, end, ALT)] of the merged calls."""
+    so = np.ascontiguousarray(seq_off, np.uint64) if seq_off is not None else None
+    sq = np.ascontiguousarray(seq, np.uint8) if seq is not None else None
+    cap = 1 << 22
+    buf = C.create_string_buffer(cap)
+    ln = C.c_uint64(0)
+    _check(load().csvhost_process_resident_chromosome_alts(ctx.h, shard.h, so.ctypes.data if so is not None else None,
+                                                           sq.ctypes.data if sq is not None else None, eps, min_pts_pct, buf, cap, C.byref(ln)))
+    out = []
+    for line in buf.raw[: ln.value].decode().split("\n")[:-1]:
+        a, b, alt = line.split("\t")
+        out.append((int(a), int(b), alt))
+    return out
 
 
 def process_resident_chromosome(ctx: Context, shard: Shard, eps: float, min_pts_pct: float, seq_off_ptr=None, seq_ptr=None, capacity: int = 1 << 20):

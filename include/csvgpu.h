@@ -248,9 +248,15 @@ int csvgpu_chr_pipeline_fetch(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen
  * ordered by the context's stream: the next chromosome's scan then starts on the device the moment this one's last copy is done.
  * csvgpu_chr_pipeline_fetch is begin + cluster + end. */
 typedef struct csv_job csv_job;
+/* At most CSV_MAX_JOBS jobs may be open (between begin and end / abort) on one context: each holds one of the context's page-locked
+ * counter slots. One more csvgpu_chr_job_begin returns NULL ("more than CSV_MAX_JOBS jobs open"). */
+#define CSV_MAX_JOBS 16
 csv_job *csvgpu_chr_job_begin(csv_ctx *ctx, csv_shard *shard, uint32_t min_oplen, uint8_t min_mapq, double min_pts_pct);
 int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host_sig, int32_t *host_labels, uint64_t capacity);
 int csvgpu_chr_job_end(csv_ctx *ctx, csv_job *job, csv_chr_result *result);
+/* Give up a job after csvgpu_chr_job_cluster (or anything between begin and end) failed: waits for what the job queued, frees it,
+ * and leaves csvgpu_last_error() as the failure left it (csvgpu_chr_job_end on an unclustered job would overwrite it). */
+int csvgpu_chr_job_abort(csv_ctx *ctx, csv_job *job);
 
 /* Several chromosomes in flight on one GPU: several contexts (one per host thread, each with its own stream) that share a gate.
  * They queue the scan + depth pair of their jobs onto the gate's ONE stream — so the bandwidth-bound kernels of all lanes run back
@@ -300,6 +306,10 @@ int csvgpu_window_log2_dev(csv_ctx *ctx, const uint32_t *d_depth, uint32_t depth
 int csvgpu_viterbi_dev(csv_ctx *ctx, const csv_hmm *hmm, const double *d_o1, const double *d_o2,
                        const double *d_pfb, const uint64_t *d_seq_off, uint64_t n_seq,
                        uint64_t n_obs, int32_t *d_states, double *d_loglik);
+
+/* Test hook: the next n guarded device allocations inside the library fail as if HBM were exhausted (error-path tests of the
+ * signature-buffer growth in csvgpu_chr_job_cluster). Not for production callers. */
+void csvgpu_test_fail_next_alloc(int n);
 
 #ifdef __cplusplus
 }

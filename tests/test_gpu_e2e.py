@@ -85,23 +85,7 @@ def _build(seed):
     return contigs
 
 
-def _full(start, end, sv_type, cluster, flags, aln_offset=None):
-    c = host.make_calls(start, end, sv_type, cluster)
-    c["aln_flags"] = flags
-    if aln_offset is not None:
-        c["aln_offset"] = aln_offset
-    return c
-
-
-def _orc_merge(oracle, full, eps, min_pts, keep_noise):
-    small = np.zeros(len(full), oracle_lib.CALL_DTYPE)
-    for f in ("start", "end", "sv_type", "cluster_size", "hmm_likelihood"):
-        small[f] = full[f]
-    small["id"] = np.arange(len(full))
-    m = oracle.merge_svs(small, eps, min_pts, keep_noise)
-    out = full[m["id"]].copy()
-    out["cluster_size"] = m["cluster_size"]
-    return out
+from oracle_chain import oracle_run
 
 
 def _write_genome(path, n_contigs, rng):
@@ -125,34 +109,7 @@ def test_whole_path_end_to_end(ctx, oracle, tmp_path):
                                       file_date="20250926", want_alts=True, save_cnv=True)
 
     # ---- the same chain from the oracle's pieces --------------------------------------------------
-    cigar_calls, depths, means = [], [], []
-    for c in contigs:
-        r = c["reads"]
-        sig = oracle.cigar_scan(r, c["depth_len"])
-        depth, s, nz = oracle.depth(r, c["depth_len"])
-        mean = s / nz
-        min_pts = int(np.ceil(mean * 0.1))
-        kind = sig["qpos_kind"] & 3
-        full = _full(sig["start"], sig["end"], np.where(kind == 1, 0, 3), 0, np.where(kind == 0, 1, np.where(kind == 1, 2, 4)))
-        full = _orc_merge(oracle, full, 0.1, min_pts, False)
-        full = oracle.cn_prediction(depth, full, hmm, mean, c["snps"], split=False)
-        cigar_calls.append(full); depths.append(depth); means.append(mean)
-    tid = np.concatenate([np.full(c["reads"].n_reads, t, np.int32) for t, c in enumerate(contigs)])
-    cat = lambda f: np.concatenate([getattr(c["reads"], f) for c in contigs])
-    iv = [oracle.aln_intervals(c["reads"]) for c in contigs]
-    sp = oracle.split_signatures(tid, cat("pos"), cat("flag"), cat("mapq"), np.concatenate([x[0] for x in iv]), np.concatenate([x[1] for x in iv]),
-                                 np.concatenate([x[2] for x in iv]), np.concatenate([c["qname_id"] for c in contigs]))
-    exp, exp_tid = [], []
-    for t, c in enumerate(contigs):
-        st = sp[sp["tid"] == t]
-        split_full = _full(st["start"], st["end"], st["sv_type"], st["cluster_size"], st["aln_flags"], st["aln_offset"])
-        if len(split_full):
-            split_full = oracle.cn_prediction(depths[t], split_full, hmm, means[t], c["snps"], split=True)
-            split_full = _orc_merge(oracle, split_full, 0.1, 2, True)
-        whole = np.concatenate([cigar_calls[t], split_full])
-        whole = _orc_merge(oracle, whole, 0.1, 2, True)
-        exp.append(whole); exp_tid.append(np.full(len(whole), t, np.int32))
-    exp, exp_tid = np.concatenate(exp), np.concatenate(exp_tid)
+    exp, exp_tid, depths, means = oracle_run(oracle, contigs, hmm)
 
     assert len(got) == len(exp) and len(got) > 20
     assert np.array_equal(got_tid, exp_tid)

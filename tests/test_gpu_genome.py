@@ -1,0 +1,89 @@
+"""SVCaller::runResident — one step of the whole-genome benchmark: every contig resident in HBM, the CIGAR pass of all contigs
+through the lanes, then the passes of SVCaller::run in the reference's order (src/sv_caller.cpp:804-945) — against (i) the
+upload-per-contig run() that test_gpu_e2e.py checks field for field against the oracle, and (ii) the oracle chain itself on the
+benchmark's own generator (shards with supplementary records, SNPs, calls >= 2 kb for the copy-number pass)."""
+import numpy as np
+import pytest
+
+import contextsv_amd as cs
+from contextsv_amd import host, make_hmm
+from hmm_params import WGS_HMM
+from oracle_chain import oracle_run
+from test_gpu_e2e import _build
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("start", "end", "sv_type", "cluster_size", "aln_flags", "genotype", "cn_state", "aln_offset")
+
+
+def _same(a, b, exact_lh=True):
+    assert len(a) == len(b)
+    for f in FIELDS:
+        assert np.array_equal(a[f], b[f]), f
+    if exact_lh:
+        assert np.array_equal(a["hmm_likelihood"], b["hmm_likelihood"])
+    else:
+        np.testing.assert_allclose(a["hmm_likelihood"], b["hmm_likelihood"], rtol=0, atol=1e-6)
+
+
+def test_resident_run_equals_uploading_run(ctx):
+    contigs = _build(11)
+    hmm = make_hmm(**WGS_HMM)
+    host.set_context(ctx)
+    ref_calls, ref_tid = host.run(ctx, contigs, hmm, eps=0.1, min_pts_pct=0.1)
+    g = host.Genome()
+    for t, c in enumerate(contigs):
+        g.add(ctx, "contig%d" % t, t, c["reads"], c["depth_len"], c["qname_id"], c["snps"], name_style=0)
+    got, tid, st, per = g.run(ctx, hmm)
+    assert np.array_equal(tid, ref_tid)
+    _same(got, ref_calls)
+    assert st.n_reads == sum(c["reads"].n_reads for c in contigs) and st.n_final_calls == len(got) and st.n_cigar_cn_regions > 0 and st.n_split_calls > 0
+    # again (nothing was consumed), with one host thread, and through three lanes behind a gate
+    got2, tid2, _, _ = g.run(ctx, hmm, host_threads=1)
+    assert np.array_equal(tid2, ref_tid)
+    _same(got2, ref_calls)
+    lanes = [cs.Context(0) for _ in range(3)]
+    gate = cs.Gate()
+    try:
+        for c in lanes:
+            c.set_gate(gate)
+        got3, tid3, st3, per3 = g.run(ctx, hmm, lanes=lanes)
+        assert np.array_equal(tid3, ref_tid)
+        _same(got3, ref_calls)
+        assert [p.n_signatures for p in per3] == [p.n_signatures for p in per]
+    finally:
+        for c in lanes:
+            c.set_gate(None)
+            c.close()
+        gate.close()
+    g.free()
+
+
+@pytest.mark.parametrize("tech,depth", [(0, 30.0), (1, 60.0)])
+def test_resident_run_on_generated_shards_equals_oracle_chain(ctx, oracle, tech, depth):
+    """Three contigs from the benchmark's generator (ONT 30x / HiFi 60x, with primary + supplementary pairs and generated SNPs),
+    staged and run resident, against the oracle's pieces composed in the reference's order."""
+    hmm = make_hmm(**WGS_HMM)
+    host.set_context(ctx)
+    lens = [1_500_000, 900_000, 1_200_000]
+    g = host.Genome()
+    contigs = []
+    for t, L in enumerate(lens):
+        syn = host.SynthShard(0xC0FFEE + 17 * t + tech, L, depth, tech, 4, sv_per_bp=1.0 / 30000.0)
+        r = syn.reads
+        reads = cs.Reads(r.pos.copy(), r.flag.copy(), r.mapq.copy(), r.cigar_off.copy(), r.cigar.copy())
+        qid = syn.qname_id.astype(np.uint32) + np.uint32(t << 24)                   # "r<id>" names must not collide across contigs
+        rng = np.random.default_rng(t)
+        n_snp = L // 1000
+        pos = np.sort(rng.choice(np.arange(1000, L - 1000), n_snp, replace=False)).astype(np.uint32)
+        snps = {"pos": pos, "baf": np.where(rng.random(n_snp) < 0.66, 0.45 + 0.1 * rng.random(n_snp), 1.0), "pfb": np.zeros(n_snp), "has_pfb": np.zeros(n_snp, np.uint8)}
+        contigs.append({"reads": reads, "depth_len": syn.depth_len, "qname_id": qid, "snps": snps})
+        g.add(ctx, "contig%d" % t, t, reads, syn.depth_len, qid, snps, name_style=0)
+        syn.free()
+    got, tid, st, per = g.run(ctx, hmm)
+    exp, exp_tid, depths, means = oracle_run(oracle, contigs, hmm)
+    assert np.array_equal(tid, exp_tid)
+    _same(got, exp, exact_lh=False)
+    assert len(got) > 10 and st.n_cigar_cn_regions > 0
+    if tech == 0:
+        assert st.n_split_calls > 0
+    g.free()
