@@ -64,7 +64,7 @@ bool timer_begin(csv_ctx *ctx, int id, hipStream_t s)
     if (!ctx->timing) return false;
     // every recorded event is a barrier packet in the queue (~5 us of idle device each): level 2 keeps them to the two groups a
     // roofline is quoted for
-    if (ctx->timing == 2 && id != CSV_K_CIGAR_SCAN && id != CSV_K_DEPTH) return false;
+    if (ctx->timing >= 2 && id != CSV_K_CIGAR_SCAN && id != CSV_K_DEPTH) return false;
     Timer t; t.id = id; t.a = get_event(ctx); t.b = get_event(ctx); t.s = s ? s : ctx->stream;
     (void)hipEventRecord(t.a, t.s);
     ctx->timers.push_back(t);
@@ -418,7 +418,7 @@ int csvgpu_synchronize(csv_ctx *ctx)
     return CSV_OK;
 }
 
-int csvgpu_timing_enable(csv_ctx *ctx, int on) { if (!ctx) return CSV_EINVAL; ctx->timing = on < 0 ? 0 : (on > 2 ? 1 : on); return CSV_OK; }
+int csvgpu_timing_enable(csv_ctx *ctx, int on) { if (!ctx) return CSV_EINVAL; ctx->timing = on < 0 ? 0 : (on > 3 ? 1 : on); return CSV_OK; }
 
 int csvgpu_timing_reset(csv_ctx *ctx)
 {
@@ -1035,7 +1035,7 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
     // timed with the two events the job records there anyway plus one in front (scan = ev_scan - t0, depth = ev_depth - ev_scan).
     // (at level 2 only every fourth pair: the extra event in front of the scan is a barrier packet on the stream all lanes share, 2.5 % of
     // the throughput when every pair has one; the averages are over the timed pairs)
-    const bool pair_timers = big != s && ctx->timing != 0 && (ctx->timing == 1 || (ctx->timer_tick++ & 3u) == 0);
+    const bool pair_timers = big != s && ctx->timing != 0 && (ctx->timing == 1 || ctx->timing == 3 || (ctx->timer_tick++ & 3u) == 0);
     hipEvent_t t0 = nullptr;
     if (pair_timers) {
         t0 = get_event(ctx);

@@ -117,7 +117,8 @@ int         csvgpu_synchronize(csv_ctx *ctx);
  * the stream the group runs on (the context's; for the scan + depth pair of a job behind a gate, the gate's — there the
  * pair shares three events, and at on = 2 only every fourth pair is timed); csvgpu_timing_get() synchronises and returns the accumulated device
  * time and the number of launch groups since the last reset. on = 1: every group; on = 2: only CSV_K_CIGAR_SCAN and
- * CSV_K_DEPTH (an event is a barrier packet in the queue, ~5 us of idle device each); on = 0: off. */
+ * CSV_K_DEPTH (an event is a barrier packet in the queue, ~5 us of idle device each); on = 3: those two groups, every pair timed also
+ * behind a gate (for runs whose launches differ in size, where a sampled quarter would not match the bytes); on = 0: off. */
 int         csvgpu_timing_enable(csv_ctx *ctx, int on);
 int         csvgpu_timing_reset(csv_ctx *ctx);
 int         csvgpu_timing_get(csv_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
