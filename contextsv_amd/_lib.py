@@ -62,6 +62,7 @@ ABI = {
     "csvgpu_aln_intervals": (C.c_int, [_P, C.POINTER(csv_reads), _P, _P, _P]),
     "csvgpu_depth": (C.c_int, [_P, C.POINTER(csv_reads), C.c_uint32, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "csvgpu_dbscan_iv": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_double, C.c_int32, _P]),
+    "csvgpu_dbscan_iv_batch": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_double, C.c_int32, _P]),
     "csvgpu_dbscan_1d": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_double, C.c_int32, _P]),
     "csvgpu_window_log2": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _P, _P, C.c_uint64, C.c_double, _P, _P, _P]),
     "csvgpu_viterbi": (C.c_int, [_P, C.POINTER(csv_hmm), _P, _P, _P, _P, C.c_uint64, _P, _P]),
@@ -81,6 +82,7 @@ ABI = {
     "csvgpu_host_alloc": (_P, [_P, C.c_size_t]),
     "csvgpu_host_free": (None, [_P, _P]),
     "csvgpu_aln_intervals_resident": (C.c_int, [_P, _P, _P, _P, _P]),
+    "csvgpu_aln_intervals_gather_resident": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P]),
     "csvgpu_window_log2_resident": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_double, _P, _P, _P]),
     "csvgpu_chr_fetch": (C.c_int, [_P, _P, C.POINTER(csv_chr_result), _P, _P]),
     "csvgpu_depth_lookup_resident": (C.c_int, [_P, _P, _P, C.c_uint64, _P]),

@@ -138,6 +138,14 @@ class Context:
         self._check(self.lib.csvgpu_dbscan_iv(self.h, ptr(start), ptr(end), n, eps, min_pts, ptr(labels)))
         return labels[:n]
 
+    def dbscan_iv_batch(self, start, end, seg_off, eps: float, min_pts: int):
+        start = np.ascontiguousarray(start, np.uint32)
+        end = np.ascontiguousarray(end, np.uint32)
+        seg_off = np.ascontiguousarray(seg_off, np.uint64)
+        labels = np.zeros(max(len(start), 1), np.int32)
+        self._check(self.lib.csvgpu_dbscan_iv_batch(self.h, ptr(start), ptr(end), ptr(seg_off), len(seg_off) - 1, eps, min_pts, ptr(labels)))
+        return labels[: len(start)]
+
     def dbscan_1d(self, pts, seg_off, eps: float, min_pts: int):
         pts = np.ascontiguousarray(pts, np.int32)
         seg_off = np.ascontiguousarray(seg_off, np.uint64)

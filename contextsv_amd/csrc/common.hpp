@@ -204,6 +204,10 @@ size_t dbscan_tmp_bytes(uint64_t n);
 // only honoured when oid == nullptr).
 void launch_dbscan_iv_sorted(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint32_t *oid,
                              uint64_t n, uint64_t split, double eps, int min_pts, const int *d_min_pts, int32_t *labels, void *tmp);
+// many small sets (caller order, at most DBSCAN_IV_SMALL_MAX points each: larger segments are skipped) in one launch, one workgroup per set
+constexpr uint32_t DBSCAN_IV_SMALL_MAX = 2048;
+void launch_dbscan_iv_small_batched(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint64_t *seg_off, uint64_t n_seg, double eps,
+                                    int min_pts, int32_t *labels);
 // dbscan1d.hip
 void launch_dbscan_1d_batched(hipStream_t s, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg,
                               double eps, int min_pts, int32_t *labels, unsigned int *too_large_flag);

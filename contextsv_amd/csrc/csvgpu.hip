@@ -564,6 +564,48 @@ int csvgpu_dbscan_iv(csv_ctx *ctx, const uint32_t *start, const uint32_t *end, u
     return CSV_OK;
 }
 
+int csvgpu_dbscan_iv_batch(csv_ctx *ctx, const uint32_t *start, const uint32_t *end, const uint64_t *seg_off, uint64_t n_seg, double eps,
+                           int32_t min_pts, int32_t *labels)
+{
+    int rc = check_dbscan_args(ctx, eps, min_pts, true);
+    if (rc) return rc;
+    if (n_seg == 0) return CSV_OK;
+    if (!seg_off) { ctx->err = "dbscan batch: null seg_off"; return CSV_EINVAL; }
+    uint64_t max_len = 0;
+    for (uint64_t s = 0; s < n_seg; s++) {
+        if (seg_off[s + 1] < seg_off[s]) { ctx->err = "dbscan batch: seg_off not monotone"; return CSV_EINVAL; }
+        max_len = std::max(max_len, seg_off[s + 1] - seg_off[s]);
+    }
+    const uint64_t n = seg_off[n_seg];
+    if (n == 0) return CSV_OK;
+    if (!start || !end || !labels) { ctx->err = "dbscan batch: null array"; return CSV_EINVAL; }
+    if (n >= 0xffffffffull) { ctx->err = "dbscan batch: n too large"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    if ((rc = arena_reserve(ctx, ctx->arena, 3 * align_up(n * 4, 256) + align_up((n_seg + 1) * 8, 256) + 1024))) return rc;
+    uint32_t *ds = (uint32_t *)arena_alloc(ctx->arena, n * 4), *de = (uint32_t *)arena_alloc(ctx->arena, n * 4);
+    int32_t *dl = (int32_t *)arena_alloc(ctx->arena, n * 4);
+    uint64_t *doff = (uint64_t *)arena_alloc(ctx->arena, (n_seg + 1) * 8);
+    if (!ds || !de || !dl || !doff) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    hipStream_t st = ctx->stream;
+    CSV_HIP(ctx, hipMemcpyAsync(ds, start, n * 4, hipMemcpyHostToDevice, st));
+    CSV_HIP(ctx, hipMemcpyAsync(de, end, n * 4, hipMemcpyHostToDevice, st));
+    CSV_HIP(ctx, hipMemcpyAsync(doff, seg_off, (n_seg + 1) * 8, hipMemcpyHostToDevice, st));
+    {
+        TimerScope ts(ctx, CSV_K_DBSCAN);
+        launch_dbscan_iv_small_batched(st, ds, de, doff, n_seg, eps, min_pts, dl);
+    }
+    if (max_len > DBSCAN_IV_SMALL_MAX) {                     // the few sets that do not fit a workgroup's LDS: windowed path, one at a time
+        for (uint64_t s = 0; s < n_seg; s++) {
+            const uint64_t len = seg_off[s + 1] - seg_off[s];
+            if (len <= DBSCAN_IV_SMALL_MAX) continue;
+            if ((rc = csvgpu_dbscan_iv_dev(ctx, ds + seg_off[s], de + seg_off[s], len, eps, min_pts, dl + seg_off[s]))) return rc;
+        }
+    }
+    CSV_HIP(ctx, hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, st));
+    CSV_HIP(ctx, hipStreamSynchronize(st));
+    return CSV_OK;
+}
+
 int csvgpu_dbscan_1d_dev(csv_ctx *ctx, const int32_t *d_pts, const uint64_t *d_seg_off, uint64_t n_seg, uint64_t n_pts,
                          uint32_t max_seg_len, double eps, int32_t min_pts, int32_t *d_labels)
 {
@@ -832,6 +874,31 @@ int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *sh, int32_t *ref_end,
     CSV_HIP(ctx, hipMemcpyAsync(q_start, sh->q_start, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     CSV_HIP(ctx, hipMemcpyAsync(q_end, sh->q_end, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
+int csvgpu_aln_intervals_gather_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *rec, uint64_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end)
+{
+    if (!ctx || !sh) return CSV_EINVAL;
+    if (n == 0) return CSV_OK;
+    if (!rec || !ref_end || !q_start || !q_end) { ctx->err = "aln_intervals_gather: null array"; return CSV_EINVAL; }
+    for (uint64_t i = 0; i < n; i++) if (rec[i] >= sh->d.n_reads) { ctx->err = "aln_intervals_gather: record index beyond the shard"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    int rc = arena_reserve(ctx, ctx->arena, 4 * align_up(n * 4, 256) + 4096);
+    if (rc) return rc;
+    uint32_t *didx = (uint32_t *)arena_alloc(ctx->arena, n * 4);
+    uint32_t *dout[3];
+    for (int k = 0; k < 3; k++) dout[k] = (uint32_t *)arena_alloc(ctx->arena, n * 4);
+    if (!didx || !dout[0] || !dout[1] || !dout[2]) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    hipStream_t s = ctx->stream;
+    CSV_HIP(ctx, hipMemcpyAsync(didx, rec, n * 4, hipMemcpyHostToDevice, s));
+    const int32_t *src[3] = {sh->ref_end, sh->q_start, sh->q_end};
+    int32_t *dst[3] = {ref_end, q_start, q_end};
+    for (int k = 0; k < 3; k++) {
+        launch_gather_u32(s, (const uint32_t *)src[k], didx, n, dout[k]);
+        CSV_HIP(ctx, hipMemcpyAsync(dst[k], dout[k], n * 4, hipMemcpyDeviceToHost, s));
+    }
+    CSV_HIP(ctx, hipStreamSynchronize(s));
     return CSV_OK;
 }
 

@@ -6,7 +6,11 @@
 #include <algorithm>
 #include <stdexcept>
 
+#include <charconv>
+
 #include "log.h"
+#include "par.h"
+#include "umap_order.h"
 
 namespace {
 void check(csv_ctx *ctx, int rc, const char *what)
@@ -38,128 +42,225 @@ Genotype CNVCaller::getGenotypeFromCNState(int cn_state)
     return Genotype::UNKNOWN;
 }
 
-void CNVCaller::querySNPRegions(const std::vector<std::pair<uint32_t, uint32_t>> &regions, csv_shard *shard, double mean_chr_cov,
-                                const SNPSource &snps, std::vector<SNPData> &out) const
-{
-    const size_t n = regions.size();
-    out.assign(n, SNPData());
+// ---- querySNPRegion, batched ---------------------------------------------------------------------------------------------------
+// One RegionBatch = the regions of one contig: (A) SNP look-ups per region, (B) ONE window launch on the contig's resident depth map,
+// (C) the observation vectors per region. A and C are independent per region and run on the host pool.
+struct CNVCaller::RegionBatch {
     struct RegionSnps { std::vector<uint32_t> pos; std::unordered_map<uint32_t, double> baf, pfb; };
-    std::vector<RegionSnps> rs(n);
+    std::vector<std::pair<uint32_t, uint32_t>> regions;
+    std::vector<RegionSnps> rs;
     std::vector<uint32_t> r_start, r_end;
     std::vector<int32_t> r_ss;
     std::vector<uint64_t> win_off{0};
-    std::vector<size_t> slot(n, SIZE_MAX);                 // region -> row of the device batch (invalid regions have none)
+    std::vector<size_t> slot;                  // region -> row of the device batch (invalid regions have none)
+    std::vector<double> log2_cov;
+    std::vector<uint32_t> ws, we;
+};
+
+void CNVCaller::prepareWindows(RegionBatch &B, const SNPSource &snps) const
+{
+    const size_t n = B.regions.size();
+    B.rs.assign(n, RegionBatch::RegionSnps());
+    B.slot.assign(n, SIZE_MAX);
+    csvhost::parallel_for(n, host_threads, [&](size_t i) { snps.query(B.regions[i].first, B.regions[i].second, B.rs[i].pos, B.rs[i].baf, B.rs[i].pfb); });
     for (size_t i = 0; i < n; i++) {
-        const uint32_t start_pos = regions[i].first, end_pos = regions[i].second;
-        snps.query(start_pos, end_pos, rs[i].pos, rs[i].baf, rs[i].pfb);
+        const uint32_t start_pos = B.regions[i].first, end_pos = B.regions[i].second;
         if (start_pos > end_pos) {                          // the reference logs and leaves snp_data empty (cnv_caller.cpp:69-73)
             printError("ERROR: Invalid SNP region for copy number prediction: " + std::to_string((int)start_pos) + "-" + std::to_string((int)end_pos));
             continue;
         }
-        const int ss = std::max((int)rs[i].pos.size(), sample_size);   // :65
-        slot[i] = r_start.size();
-        r_start.push_back(start_pos); r_end.push_back(end_pos); r_ss.push_back(ss);
-        win_off.push_back(win_off.back() + (uint64_t)ss);
+        const int ss = std::max((int)B.rs[i].pos.size(), sample_size);   // :65
+        B.slot[i] = B.r_start.size();
+        B.r_start.push_back(start_pos); B.r_end.push_back(end_pos); B.r_ss.push_back(ss);
+        B.win_off.push_back(B.win_off.back() + (uint64_t)ss);
     }
-    const uint64_t nw = win_off.back();
-    std::vector<double> log2_cov(nw);
-    std::vector<uint32_t> ws(nw), we(nw);
-    if (!r_start.empty())
-        check(ctx, csvgpu_window_log2_resident(ctx, shard, r_start.data(), r_end.data(), r_ss.data(), win_off.data(), r_start.size(), mean_chr_cov,
-                                               log2_cov.data(), ws.data(), we.data()), "querySNPRegion");
-    for (size_t i = 0; i < n; i++) {
-        if (slot[i] == SIZE_MAX) continue;
-        const uint64_t w0 = win_off[slot[i]], w1 = win_off[slot[i] + 1];
-        // the reference keys the windows by the string "ws-we" in an unordered_map: equal keys collapse (later window
-        // wins) and the iteration order of that libstdc++ container is the observation order (:77, :111-112, :124)
-        std::unordered_map<std::string, double> window_log2_map;
-        for (uint64_t w = w0; w < w1; w++) window_log2_map[std::to_string(ws[w]) + "-" + std::to_string(we[w])] = log2_cov[w];
-        SNPData &d = out[i];
-        RegionSnps &r = rs[i];
-        for (const auto &window : window_log2_map) {
-            const uint32_t window_start = (uint32_t)std::stoi(window.first.substr(0, window.first.find('-')));
-            const uint32_t window_end = (uint32_t)std::stoi(window.first.substr(window.first.find('-') + 1));
-            const double l2 = window.second;
-            bool snp_found = false;
-            for (uint32_t pos : r.pos) {
-                if (pos >= window_start && pos <= window_end) {        // inclusive both ends: a SNP can land in two windows (:132)
-                    d.pos.push_back(pos); d.baf.push_back(r.baf[pos]); d.pfb.push_back(r.pfb[pos]);
-                    d.log2_cov.push_back(l2); d.is_snp.push_back(true);
-                    snp_found = true;
-                }
-            }
-            if (!snp_found) {                                           // dummy observation at the window centre (:144-155)
-                d.pos.push_back((window_start + window_end) / 2); d.baf.push_back(-1.0); d.pfb.push_back(0.5);
-                d.log2_cov.push_back(l2); d.is_snp.push_back(false);
+}
+
+void CNVCaller::launchWindows(RegionBatch &B, csv_shard *shard, double mean_chr_cov) const
+{
+    const uint64_t nw = B.win_off.back();
+    B.log2_cov.resize(nw); B.ws.resize(nw); B.we.resize(nw);
+    if (!B.r_start.empty())
+        check(ctx, csvgpu_window_log2_resident(ctx, shard, B.r_start.data(), B.r_end.data(), B.r_ss.data(), B.win_off.data(), B.r_start.size(), mean_chr_cov,
+                                               B.log2_cov.data(), B.ws.data(), B.we.data()), "querySNPRegion");
+}
+
+// The reference keys the windows by the string "ws-we" in an unordered_map<std::string,double>: equal keys collapse (the later window's
+// value wins, the node stays where the first put it) and the iteration order of that libstdc++ container is the observation order
+// (:77, :111-112, :124). The order is replayed by UMapOrder on the keys' hashes (umap_order.h) — no strings, no nodes.
+void CNVCaller::assembleRegion(const RegionBatch &B, size_t i, SNPData &d) const
+{
+    if (B.slot[i] == SIZE_MAX) return;
+    const uint64_t w0 = B.win_off[B.slot[i]], w1 = B.win_off[B.slot[i] + 1];
+    static thread_local csvhost::UMapOrder order;
+    static thread_local std::vector<uint64_t> first_w, last_w;            // by node: the window that created the key / that wrote it last
+    order.clear(); first_w.clear(); last_w.clear();
+    for (uint64_t w = w0; w < w1; w++) {
+        char key[24];
+        char *e = std::to_chars(key, key + 11, B.ws[w]).ptr;
+        *e++ = '-';
+        e = std::to_chars(e, e + 11, B.we[w]).ptr;
+        const uint64_t h = csvhost::std_string_hash(key, (size_t)(e - key));
+        const int64_t node = order.find(h, [&](uint32_t nd) { return B.ws[first_w[nd]] == B.ws[w] && B.we[first_w[nd]] == B.we[w]; });
+        if (node >= 0) { last_w[(size_t)node] = w; continue; }
+        order.insert_new(h);
+        first_w.push_back(w); last_w.push_back(w);
+    }
+    const RegionBatch::RegionSnps &r = B.rs[i];
+    const size_t guess = order.size() + r.pos.size();
+    d.pos.reserve(guess); d.baf.reserve(guess); d.pfb.reserve(guess); d.log2_cov.reserve(guess); d.is_snp.reserve(guess);
+    order.for_each([&](uint32_t node) {
+        const uint32_t window_start = B.ws[first_w[node]], window_end = B.we[first_w[node]];
+        const double l2 = B.log2_cov[last_w[node]];
+        bool snp_found = false;
+        for (uint32_t pos : r.pos) {
+            if (pos >= window_start && pos <= window_end) {        // inclusive both ends: a SNP can land in two windows (:132)
+                const auto b = r.baf.find(pos), f = r.pfb.find(pos);
+                d.pos.push_back(pos); d.baf.push_back(b != r.baf.end() ? b->second : 0.0); d.pfb.push_back(f != r.pfb.end() ? f->second : 0.0);   // operator[]: 0.0 when absent (:138)
+                d.log2_cov.push_back(l2); d.is_snp.push_back(true);
+                snp_found = true;
             }
         }
-    }
+        if (!snp_found) {                                           // dummy observation at the window centre (:144-155)
+            d.pos.push_back((window_start + window_end) / 2); d.baf.push_back(-1.0); d.pfb.push_back(0.5);
+            d.log2_cov.push_back(l2); d.is_snp.push_back(false);
+        }
+    });
+}
+
+void CNVCaller::querySNPRegions(const std::vector<std::pair<uint32_t, uint32_t>> &regions, csv_shard *shard, double mean_chr_cov,
+                                const SNPSource &snps, std::vector<SNPData> &out) const
+{
+    RegionBatch B;
+    B.regions = regions;
+    prepareWindows(B, snps);
+    launchWindows(B, shard, mean_chr_cov);
+    out.assign(regions.size(), SNPData());
+    csvhost::parallel_for(regions.size(), host_threads, [&](size_t i) { assembleRegion(B, i, out[i]); });
+}
+
+// all sequences of `data` through ONE Viterbi launch; states come back flat (sequence q = [seq_off[q], seq_off[q + 1]))
+void CNVCaller::runViterbiFlat(const CHMM &hmm, const std::vector<const SNPData *> &data, std::vector<uint64_t> &seq_off, std::vector<int> &states,
+                               std::vector<double> &loglik) const
+{
+    const size_t n = data.size();
+    seq_off.assign(n + 1, 0);
+    for (size_t q = 0; q < n; q++) seq_off[q + 1] = seq_off[q] + data[q]->pos.size();
+    VitBatch b;
+    b.o1.resize(seq_off[n]); b.o2.resize(seq_off[n]); b.pfb.resize(seq_off[n]);
+    b.seq_off = seq_off;
+    csvhost::parallel_for(n, host_threads, [&](size_t q) {
+        const SNPData &d = *data[q];
+        std::copy(d.log2_cov.begin(), d.log2_cov.end(), b.o1.begin() + (std::ptrdiff_t)seq_off[q]);
+        std::copy(d.baf.begin(), d.baf.end(), b.o2.begin() + (std::ptrdiff_t)seq_off[q]);
+        std::copy(d.pfb.begin(), d.pfb.end(), b.pfb.begin() + (std::ptrdiff_t)seq_off[q]);
+    });
+    testVit_CHMM_batch(hmm, b, states, loglik);
+    for (size_t q = 0; q < n; q++)
+        if (data[q]->pos.empty()) printError("ERROR: No SNP data found for Viterbi algorithm.");      // runViterbi logs and still calls testVit_CHMM with T = 0 (:43-49)
 }
 
 void CNVCaller::runViterbi(const CHMM &hmm, const std::vector<SNPData> &data, std::vector<std::pair<std::vector<int>, double>> &predictions) const
 {
-    VitBatch b;
-    for (const SNPData &d : data) b.add(d.log2_cov, d.baf, d.pfb);
+    std::vector<const SNPData *> ptr(data.size());
+    for (size_t i = 0; i < data.size(); i++) ptr[i] = &data[i];
+    std::vector<uint64_t> off;
     std::vector<int> states;
     std::vector<double> ll;
-    testVit_CHMM_batch(hmm, b, states, ll);
+    runViterbiFlat(hmm, ptr, off, states, ll);
     predictions.resize(data.size());
-    for (size_t i = 0; i < data.size(); i++) {
-        if (data[i].pos.empty()) {                                      // runViterbi logs and still calls testVit_CHMM with T = 0 (:43-49)
-            printError("ERROR: No SNP data found for Viterbi algorithm.");
-            predictions[i] = std::make_pair(std::vector<int>(), ll[i]);
-            continue;
-        }
-        predictions[i] = std::make_pair(std::vector<int>(states.begin() + b.seq_off[i], states.begin() + b.seq_off[i + 1]), ll[i]);
+    for (size_t i = 0; i < data.size(); i++)
+        predictions[i] = std::make_pair(std::vector<int>(states.begin() + (std::ptrdiff_t)off[i], states.begin() + (std::ptrdiff_t)off[i + 1]), ll[i]);
+}
+
+// cnv_caller.cpp:337-384 for one candidate given its observations and state path
+void CNVCaller::applyCIGARPrediction(const std::string &chr, SVCall &sv_call, const SNPData &snp_data, const int *state_sequence, size_t T, double likelihood) const
+{
+    if (snp_data.pos.empty()) {
+        printError("ERROR: No SNP data found for Viterbi algorithm for CIGAR SV at " + chr + ":" + std::to_string((int)sv_call.start) + "-" + std::to_string((int)sv_call.end));
+        return;
+    }
+    int counts[7] = {0, 0, 0, 0, 0, 0, 0}, n_in = 0;                // states of observations inside [start,end] (:337-346)
+    for (size_t i = 0; i < T; i++)
+        if (snp_data.pos[i] >= sv_call.start && snp_data.pos[i] <= sv_call.end) { counts[state_sequence[i]]++; n_in++; }
+    int max_state = 0, max_count = 0;                                // first maximum wins (:350-360)
+    for (int s = 1; s <= 6; s++) if (counts[s] > max_count) { max_state = s; max_count = counts[s]; }
+    if ((double)max_count / (double)n_in < 0.50) max_state = 0;      // :363-367 (0/0 -> NaN < 0.5 is false, as in the reference)
+    const Genotype genotype = getGenotypeFromCNState(max_state);
+    SVType updated = getSVTypeFromCNState(max_state);
+    updated = (updated == SVType::LOH) ? sv_call.sv_type : updated;  // :375
+    if (isValidCopyNumberUpdate(sv_call.sv_type, updated)) {
+        sv_call.sv_type = updated;
+        sv_call.aln_type.set((size_t)SVDataType::HMM);
+        sv_call.hmm_likelihood = likelihood;
+        sv_call.genotype = genotype;
+        sv_call.cn_state = max_state;
     }
 }
 
 size_t CNVCaller::runCIGARCopyNumberPrediction(const std::string &chr, std::vector<SVCall> &sv_candidates, const CHMM &hmm, double mean_chr_cov,
-                                             csv_shard *shard, const SNPSource &snps) const
+                                               csv_shard *shard, const SNPSource &snps) const
 {
-    std::vector<size_t> idx;
-    std::vector<std::pair<uint32_t, uint32_t>> regions;
-    for (size_t k = 0; k < sv_candidates.size(); k++) {
-        const SVCall &c = sv_candidates[k];
-        if (c.start > c.end) {
-            printError("ERROR: Invalid SV region for copy number prediction: " + chr + ":" + std::to_string((int)c.start) + "-" + std::to_string((int)c.end));
-            continue;
-        }
-        if ((c.end - c.start) < min_cnv_length) continue;               // :315
-        idx.push_back(k); regions.emplace_back(c.start, c.end);
-    }
-    if (idx.empty()) return 0;
-    std::vector<SNPData> data;
-    querySNPRegions(regions, shard, mean_chr_cov, snps, data);
-    std::vector<std::pair<std::vector<int>, double>> pred;
-    runViterbi(hmm, data, pred);
-    for (size_t q = 0; q < idx.size(); q++) {
-        SVCall &sv_call = sv_candidates[idx[q]];
-        const SNPData &snp_data = data[q];
-        if (snp_data.pos.empty()) {
-            printError("ERROR: No SNP data found for Viterbi algorithm for CIGAR SV at " + chr + ":" + std::to_string((int)sv_call.start) + "-" + std::to_string((int)sv_call.end));
-            continue;
-        }
-        const std::vector<int> &state_sequence = pred[q].first;
-        const double likelihood = pred[q].second;
-        int counts[7] = {0, 0, 0, 0, 0, 0, 0}, n_in = 0;                // states of observations inside [start,end] (:337-346)
-        for (size_t i = 0; i < state_sequence.size(); i++)
-            if (snp_data.pos[i] >= sv_call.start && snp_data.pos[i] <= sv_call.end) { counts[state_sequence[i]]++; n_in++; }
-        int max_state = 0, max_count = 0;                                // first maximum wins (:350-360)
-        for (int s = 1; s <= 6; s++) if (counts[s] > max_count) { max_state = s; max_count = counts[s]; }
-        if ((double)max_count / (double)n_in < 0.50) max_state = 0;      // :363-367 (0/0 -> NaN < 0.5 is false, as in the reference)
-        const Genotype genotype = getGenotypeFromCNState(max_state);
-        SVType updated = getSVTypeFromCNState(max_state);
-        updated = (updated == SVType::LOH) ? sv_call.sv_type : updated;  // :375
-        if (isValidCopyNumberUpdate(sv_call.sv_type, updated)) {
-            sv_call.sv_type = updated;
-            sv_call.aln_type.set((size_t)SVDataType::HMM);
-            sv_call.hmm_likelihood = likelihood;
-            sv_call.genotype = genotype;
-            sv_call.cn_state = max_state;
+    std::vector<ContigJob> one(1);
+    one[0].chr = chr; one[0].calls = &sv_candidates; one[0].mean_chr_cov = mean_chr_cov; one[0].shard = shard; one[0].snps = &snps;
+    return runCIGARCopyNumberPredictionAll(one, hmm);
+}
+
+// Every contig's candidates in one go: window launches contig by contig (each on its own resident depth map), the observation
+// vectors of ALL candidates assembled on the host pool, ONE Viterbi launch, the votes on the pool.
+size_t CNVCaller::runCIGARCopyNumberPredictionAll(std::vector<ContigJob> &jobs, const CHMM &hmm) const
+{
+    struct Cand { size_t job, call, region; };
+    std::vector<Cand> cands;
+    std::vector<RegionBatch> batches(jobs.size());
+    for (size_t j = 0; j < jobs.size(); j++) {
+        std::vector<SVCall> &v = *jobs[j].calls;
+        for (size_t k = 0; k < v.size(); k++) {
+            const SVCall &c = v[k];
+            if (c.start > c.end) {
+                printError("ERROR: Invalid SV region for copy number prediction: " + jobs[j].chr + ":" + std::to_string((int)c.start) + "-" + std::to_string((int)c.end));
+                continue;
+            }
+            if ((c.end - c.start) < min_cnv_length) continue;               // :315
+            cands.push_back(Cand{j, k, batches[j].regions.size()});
+            batches[j].regions.emplace_back(c.start, c.end);
         }
     }
-    return idx.size();
+    if (cands.empty()) return 0;
+    for (size_t j = 0; j < jobs.size(); j++) {
+        if (batches[j].regions.empty()) continue;
+        prepareWindows(batches[j], *jobs[j].snps);
+        launchWindows(batches[j], jobs[j].shard, jobs[j].mean_chr_cov);
+    }
+    std::vector<SNPData> data(cands.size());
+    csvhost::parallel_for(cands.size(), host_threads, [&](size_t q) { assembleRegion(batches[cands[q].job], cands[q].region, data[q]); });
+    std::vector<const SNPData *> ptr(cands.size());
+    for (size_t q = 0; q < cands.size(); q++) ptr[q] = &data[q];
+    std::vector<uint64_t> off;
+    std::vector<int> states;
+    std::vector<double> ll;
+    runViterbiFlat(hmm, ptr, off, states, ll);
+    csvhost::parallel_for(cands.size(), host_threads, [&](size_t q) {
+        applyCIGARPrediction(jobs[cands[q].job].chr, (*jobs[cands[q].job].calls)[cands[q].call], data[q], states.data() + off[q], (size_t)(off[q + 1] - off[q]), ll[q]);
+    });
+    return cands.size();
+}
+
+// cnv_caller.cpp:214-238: the state a split-read region is given from its path: the largest non-neutral share if above 0.3, else
+// neutral if its share is above 0.3, else 0
+int CNVCaller::splitVote(const int *seq, size_t T)
+{
+    double pct[7] = {0, 0, 0, 0, 0, 0, 0};
+    const double state_count = (double)T;
+    double largest_non_neutral_pct = 0.0; int non_neutral_state = 0;
+    for (int i = 0; i < 6; i++) {                                    // :214-224
+        pct[i + 1] = (double)std::count(seq, seq + T, i + 1) / state_count;
+        if (i + 1 != 3 && pct[i + 1] > largest_non_neutral_pct) { largest_non_neutral_pct = pct[i + 1]; non_neutral_state = i + 1; }
+    }
+    int max_state = 0;
+    if (largest_non_neutral_pct > 0.3) max_state = non_neutral_state;   // :227-238
+    else if (pct[3] > 0.3) max_state = 3;
+    return max_state;
 }
 
 void CNVCaller::runCopyNumberPredictions(const std::string &chr, const CHMM &hmm, const std::vector<std::pair<uint32_t, uint32_t>> &regions,
@@ -200,16 +301,7 @@ void CNVCaller::runCopyNumberPredictions(const std::string &chr, const CHMM &hmm
     for (size_t q = 0; q < idx.size(); q++) {
         std::vector<int> &seq = pred[q].first;
         if (seq.empty()) continue;                                       // :206-209
-        double pct[7] = {0, 0, 0, 0, 0, 0, 0};
-        const double state_count = (double)seq.size();
-        double largest_non_neutral_pct = 0.0; int non_neutral_state = 0;
-        for (int i = 0; i < 6; i++) {                                    // :214-224
-            pct[i + 1] = (double)std::count(seq.begin(), seq.end(), i + 1) / state_count;
-            if (i + 1 != 3 && pct[i + 1] > largest_non_neutral_pct) { largest_non_neutral_pct = pct[i + 1]; non_neutral_state = i + 1; }
-        }
-        int max_state = 0;
-        if (largest_non_neutral_pct > 0.3) max_state = non_neutral_state;   // :227-238
-        else if (pct[3] > 0.3) max_state = 3;
+        const int max_state = splitVote(seq.data(), seq.size());
         const SVType predicted = getSVTypeFromCNState(max_state);
         results[idx[q]] = std::make_tuple(pred[q].second, predicted, getGenotypeFromCNState(max_state), max_state);
 
@@ -290,7 +382,60 @@ void CNVCaller::runSplitReadCopyNumberPredictions(const std::string &chr, std::v
     for (const SVCall &c : split_sv_calls) regions.emplace_back(c.start, c.end);
     std::vector<std::tuple<double, SVType, Genotype, int>> results;
     runCopyNumberPredictions(chr, hmm, regions, mean_chr_cov, shard, snps, results, depth_len);
+    applySplitPredictions(split_sv_calls, results);
+}
 
+// Every contig's split-read candidates in one go (no --save-cnv records: those are written region by region in the reference's order
+// by the per-contig form above): window launches contig by contig, all observation vectors on the host pool, ONE Viterbi launch.
+void CNVCaller::runSplitReadCopyNumberPredictionsAll(std::vector<ContigJob> &jobs, const CHMM &hmm) const
+{
+    if (save_cnv_data) {
+        for (ContigJob &j : jobs) runSplitReadCopyNumberPredictions(j.chr, *j.calls, hmm, j.mean_chr_cov, j.shard, *j.snps, j.depth_len);
+        return;
+    }
+    struct Cand { size_t job, call, region; };
+    std::vector<Cand> cands;
+    std::vector<RegionBatch> batches(jobs.size());
+    std::vector<std::vector<std::tuple<double, SVType, Genotype, int>>> results(jobs.size());
+    for (size_t j = 0; j < jobs.size(); j++) {
+        const std::vector<SVCall> &v = *jobs[j].calls;
+        results[j].assign(v.size(), std::make_tuple(0.0, SVType::UNKNOWN, Genotype::UNKNOWN, 0));
+        for (size_t k = 0; k < v.size(); k++) {
+            if (v[k].start > v[k].end) {                                  // :169-173
+                printError("ERROR: Invalid SV region for copy number prediction: " + jobs[j].chr + ":" + std::to_string((int)v[k].start) + "-" + std::to_string((int)v[k].end));
+                continue;
+            }
+            cands.push_back(Cand{j, k, batches[j].regions.size()});
+            batches[j].regions.emplace_back(v[k].start, v[k].end);
+        }
+    }
+    if (!cands.empty()) {
+        for (size_t j = 0; j < jobs.size(); j++) {
+            if (batches[j].regions.empty()) continue;
+            prepareWindows(batches[j], *jobs[j].snps);
+            launchWindows(batches[j], jobs[j].shard, jobs[j].mean_chr_cov);
+        }
+        std::vector<SNPData> data(cands.size());
+        csvhost::parallel_for(cands.size(), host_threads, [&](size_t q) { assembleRegion(batches[cands[q].job], cands[q].region, data[q]); });
+        std::vector<const SNPData *> ptr(cands.size());
+        for (size_t q = 0; q < cands.size(); q++) ptr[q] = &data[q];
+        std::vector<uint64_t> off;
+        std::vector<int> states;
+        std::vector<double> ll;
+        runViterbiFlat(hmm, ptr, off, states, ll);
+        for (size_t q = 0; q < cands.size(); q++) {
+            const size_t T = (size_t)(off[q + 1] - off[q]);
+            if (T == 0) continue;                                         // :206-209
+            const int max_state = splitVote(states.data() + off[q], T);
+            results[cands[q].job][cands[q].call] = std::make_tuple(ll[q], getSVTypeFromCNState(max_state), getGenotypeFromCNState(max_state), max_state);
+        }
+    }
+    for (size_t j = 0; j < jobs.size(); j++) applySplitPredictions(*jobs[j].calls, results[j]);
+}
+
+// sv_caller.cpp:995-1063: what a split-read candidate takes from its region's prediction
+void CNVCaller::applySplitPredictions(std::vector<SVCall> &split_sv_calls, const std::vector<std::tuple<double, SVType, Genotype, int>> &results)
+{
     auto take_prediction = [](SVCall &c, double lh, Genotype g, int cn) {
         c.aln_type.set((size_t)SVDataType::HMM); c.hmm_likelihood = lh; c.genotype = g; c.cn_state = cn;
     };

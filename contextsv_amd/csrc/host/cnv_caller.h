@@ -79,10 +79,35 @@ public:
                                 const std::string &sv_type, double likelihood, const std::string &filepath) const;
     static void closeJSON(const std::string &filepath);
 
+    // One contig's share of a genome-wide copy-number pass.
+    struct ContigJob {
+        std::string chr;
+        std::vector<SVCall> *calls = nullptr;
+        double mean_chr_cov = 0.0;
+        csv_shard *shard = nullptr;
+        const SNPSource *snps = nullptr;
+        uint32_t depth_len = 0;
+    };
+    // runCIGARCopyNumberPrediction / runSplitReadCopyNumberPredictions for every contig of a run at once: the window launches go
+    // contig by contig (each on its own resident depth map), the observation vectors of all candidates are assembled on the host
+    // pool, and ONE Viterbi launch covers the genome. Same results as the per-contig forms.
+    size_t runCIGARCopyNumberPredictionAll(std::vector<ContigJob> &jobs, const CHMM &hmm) const;
+    void runSplitReadCopyNumberPredictionsAll(std::vector<ContigJob> &jobs, const CHMM &hmm) const;
+    int host_threads = 0;            // host pool threads for the per-region work (0: all); results do not depend on it
+
     // sv_caller.cpp:983-1064 — the five-way update / duplicate rule for split-read candidates
     void runSplitReadCopyNumberPredictions(const std::string &chr, std::vector<SVCall> &split_sv_calls, const CHMM &hmm,
                                            double mean_chr_cov, csv_shard *shard, const SNPSource &snps, uint32_t depth_len = 0) const;
 
 private:
     csv_ctx *ctx;
+    struct RegionBatch;
+    void prepareWindows(RegionBatch &B, const SNPSource &snps) const;
+    void launchWindows(RegionBatch &B, csv_shard *shard, double mean_chr_cov) const;
+    void assembleRegion(const RegionBatch &B, size_t i, SNPData &d) const;
+    void runViterbiFlat(const CHMM &hmm, const std::vector<const SNPData *> &data, std::vector<uint64_t> &seq_off, std::vector<int> &states,
+                        std::vector<double> &loglik) const;
+    void applyCIGARPrediction(const std::string &chr, SVCall &sv_call, const SNPData &snp_data, const int *state_sequence, size_t T, double likelihood) const;
+    static int splitVote(const int *seq, size_t T);
+    static void applySplitPredictions(std::vector<SVCall> &split_sv_calls, const std::vector<std::tuple<double, SVType, Genotype, int>> &results);
 };

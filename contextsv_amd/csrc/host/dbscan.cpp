@@ -41,6 +41,19 @@ void DBSCAN::fit(const std::vector<SVCall> &sv_calls)
     if (n) check(csvgpu_dbscan_iv(csvhost::context(), s.data(), e.data(), n, epsilon, minPts, clusters.data()), "DBSCAN::fit");
 }
 
+void DBSCAN::fitBatch(const std::vector<const std::vector<SVCall> *> &sets, double epsilon, int minPts, std::vector<std::vector<int>> &labels)
+{
+    std::vector<uint64_t> off(sets.size() + 1, 0);
+    for (size_t k = 0; k < sets.size(); k++) off[k + 1] = off[k] + sets[k]->size();
+    std::vector<uint32_t> s(off.back()), e(off.back());
+    std::vector<int> lab(off.back(), -1);
+    for (size_t k = 0; k < sets.size(); k++)
+        for (size_t i = 0; i < sets[k]->size(); i++) { s[off[k] + i] = (*sets[k])[i].start; e[off[k] + i] = (*sets[k])[i].end; }
+    if (!s.empty()) check(csvgpu_dbscan_iv_batch(csvhost::context(), s.data(), e.data(), off.data(), sets.size(), epsilon, minPts, lab.data()), "DBSCAN::fitBatch");
+    labels.resize(sets.size());
+    for (size_t k = 0; k < sets.size(); k++) labels[k].assign(lab.begin() + (std::ptrdiff_t)off[k], lab.begin() + (std::ptrdiff_t)off[k + 1]);
+}
+
 void DBSCAN1D::fit(const std::vector<int> &points)
 {
     clusters.assign(points.size(), -1);

@@ -18,6 +18,9 @@ public:
     void fit(const std::vector<SVCall> &sv_calls);
     const std::vector<int> &getClusters() const { return clusters; }
 
+    // batched form: one device call for many interval sets (set k = sets[k]'s (start, end) pairs, labels[k] per set in its order)
+    static void fitBatch(const std::vector<const std::vector<SVCall> *> &sets, double epsilon, int minPts, std::vector<std::vector<int>> &labels);
+
 private:
     double epsilon;
     int minPts;

@@ -11,6 +11,7 @@
 
 #include "dbscan.h"
 #include "log.h"
+#include "par.h"
 #include "umap_order.h"
 
 namespace {
@@ -115,10 +116,14 @@ struct SuppRef { uint64_t hash; uint64_t ord; uint32_t contig; uint32_t rec; }; 
 struct ContigWork {
     const SplitContig *in = nullptr;
     csvhost::UMapOrder order;                      // chr_primary_map's node list, all primaries
-    std::vector<PrimaryAlignment> prim;            // by node
-    std::vector<uint32_t> first_rec;               // by node: the record that created the key
+    std::vector<uint32_t> first_rec, last_rec;     // by node: the record that created the key / the last record of that name (its values win)
     std::vector<SuppRef> supps;                    // this contig's supplementary records, file order
     // survivors (primaries with a supplementary record) in the map's iteration order
+    std::vector<uint32_t> member_rec;                                  // the primary record
+    std::vector<std::pair<uint32_t, uint32_t>> member_supp_ref;       // (contig, record) of the supplementary records, all members back to back
+    std::vector<size_t> member_supp_off;                               // end of member m's supplementary records in member_supp_ref
+    std::vector<uint32_t> need;                                        // records whose intervals are gathered (sorted)
+    std::vector<int32_t> got[3];
     std::vector<PrimaryAlignment> member;
     std::vector<std::vector<SuppAlignment>> member_supps;
     std::vector<Group> groups;
@@ -128,22 +133,7 @@ struct ContigWork {
 };
 
 template <class F>
-void parallel_over(size_t n, int threads, F f)
-{
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t T = threads > 0 ? (size_t)threads : (size_t)(hw ? hw : 1);
-    T = std::max<size_t>(1, std::min(T, n));
-    if (T == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-    std::atomic<size_t> next{0};
-    std::vector<std::exception_ptr> errs(T);
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < T; t++)
-        th.emplace_back([&, t] {
-            try { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); } catch (...) { errs[t] = std::current_exception(); }
-        });
-    for (auto &x : th) x.join();
-    for (auto &e : errs) if (e) std::rethrow_exception(e);
-}
+void parallel_over(size_t n, int threads, F f) { csvhost::parallel_for(n, threads, f); }
 
 }  // namespace
 
@@ -151,7 +141,8 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
                            std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
 {
     for (const SplitContig &c : contigs)
-        if (c.n && (!c.qhash || (!c.name_id && !(c.name_bytes && c.name_off)))) throw std::runtime_error("findSplitSVSignatures: a contig without query-name hashes or identities");
+        if (c.n && (!c.qhash || (!c.name_id && !(c.name_bytes && c.name_off)) || (!c.intervals && !(c.ref_end && c.q_start && c.q_end))))
+            throw std::runtime_error("findSplitSVSignatures: a contig without query-name hashes / identities or without alignment intervals");
     // larger contigs first: the wall time of a parallel phase is the largest contig's
     std::vector<size_t> by_size(contigs.size());
     for (size_t i = 0; i < by_size.size(); i++) by_size[i] = i;
@@ -172,14 +163,13 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
             const uint16_t flag = C.flag[i];
             if ((flag & (FLAG_SECONDARY | FLAG_UNMAP | FLAG_DUP | FLAG_QCFAIL)) || C.mapq[i] < params.min_mapq) continue;
             if (flag & FLAG_SUPP) { W.supps.push_back(SuppRef{C.qhash[i], C.file_idx ? C.file_idx[i] : (((uint64_t)by_size[k] << 40) | i), (uint32_t)by_size[k], (uint32_t)i}); continue; }
-            const PrimaryAlignment p{C.pos[i] + 1, C.ref_end[i], C.q_start[i], C.q_end[i], !(flag & FLAG_REVERSE), 0};
             const int64_t node = W.order.find(C.qhash[i], [&](uint32_t nd) { return same_name(C, W.first_rec[nd], C, i); });
-            if (node >= 0) { W.prim[(size_t)node] = p; continue; }                       // operator[]: a later record of the name wins (:152)
+            if (node >= 0) { W.last_rec[(size_t)node] = (uint32_t)i; continue; }        // operator[]: a later record of the name wins (:152)
             W.order.insert_new(C.qhash[i]);
-            W.prim.push_back(p);
             W.first_rec.push_back((uint32_t)i);
+            W.last_rec.push_back((uint32_t)i);
         }
-        W.n_primary = W.prim.size();
+        W.n_primary = W.first_rec.size();
     });
 
     // ---- supp_map: every supplementary record of the run by name, file order within a name (:162-165) ---------------------------
@@ -187,29 +177,61 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     for (const ContigWork &W : work) supp_index.insert(supp_index.end(), W.supps.begin(), W.supps.end());
     std::sort(supp_index.begin(), supp_index.end(), [](const SuppRef &a, const SuppRef &b) { return a.hash != b.hash ? a.hash < b.hash : a.ord < b.ord; });
 
-    // ---- phase 2: survivors in iteration order, interval tree, overlap groups, the six point sets (:183-347), per contig ---------
+    // ---- survivors (primaries with a supplementary record, :183-202) in the map's iteration order, with their supplementary records ----
     std::atomic<long> total_removed{0};
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         ContigWork &W = work[by_size[k]];
         const SplitContig &C = *W.in;
-        const int primary_tid = C.tid;
         W.order.for_each([&](uint32_t node) {
             const uint64_t h = C.qhash[W.first_rec[node]];
             auto lo = std::lower_bound(supp_index.begin(), supp_index.end(), h, [](const SuppRef &a, uint64_t x) { return a.hash < x; });
-            std::vector<SuppAlignment> mine;
-            for (; lo != supp_index.end() && lo->hash == h; ++lo) {
-                const SplitContig &S = *work[lo->contig].in;
-                if (!same_name(C, W.first_rec[node], S, lo->rec)) continue;              // equal hash, different name
-                const uint32_t r = lo->rec;
-                mine.push_back(SuppAlignment{S.tid, S.pos[r] + 1, S.ref_end[r], S.q_start[r], S.q_end[r], !(S.flag[r] & FLAG_REVERSE)});
-            }
-            if (mine.empty()) return;                                                   // erased: no supplementary record (:183-202)
-            W.member.push_back(W.prim[node]);
-            W.member_supps.push_back(std::move(mine));
+            const size_t before = W.member_supp_ref.size();
+            for (; lo != supp_index.end() && lo->hash == h; ++lo)
+                if (same_name(C, W.first_rec[node], *work[lo->contig].in, lo->rec)) W.member_supp_ref.push_back(std::make_pair(lo->contig, lo->rec));   // (equal hash, other name: skipped)
+            if (W.member_supp_ref.size() == before) return;                             // erased: no supplementary record
+            W.member_rec.push_back(W.last_rec[node]);
+            W.member_supp_off.push_back(W.member_supp_ref.size());
         });
-        total_removed += (long)(W.n_primary - W.member.size());
-        // the map's storage is not needed any more
-        W.order = csvhost::UMapOrder(); W.prim = {}; W.first_rec = {};
+        total_removed += (long)(W.n_primary - W.member_rec.size());
+        W.order = csvhost::UMapOrder(); W.first_rec = {}; W.last_rec = {};             // the map's storage is not needed any more
+    });
+
+    // ---- the alignment intervals of the records that are left (ref_end / q_start / q_end of the scan kernel): straight from the
+    // arrays, or — contigs that carry an IntervalSource — gathered for just these records (a few per cent of the contig's) ----------
+    for (ContigWork &W : work) {
+        const SplitContig &C = *W.in;
+        if (C.ref_end || !C.intervals) continue;
+        for (uint32_t r : W.member_rec) W.need.push_back(r);
+        for (const SuppRef &sr : W.supps) W.need.push_back(sr.rec);
+        std::sort(W.need.begin(), W.need.end());
+        W.need.erase(std::unique(W.need.begin(), W.need.end()), W.need.end());
+        for (int a = 0; a < 3; a++) W.got[a].resize(W.need.size());
+        if (!W.need.empty()) C.intervals->gather(W.need.data(), W.need.size(), W.got[0].data(), W.got[1].data(), W.got[2].data());
+    }
+    auto interval = [&](const ContigWork &W, uint32_t rec, int which) -> int32_t {
+        const SplitContig &C = *W.in;
+        if (C.ref_end) return which == 0 ? C.ref_end[rec] : (which == 1 ? C.q_start[rec] : C.q_end[rec]);
+        const size_t slot = (size_t)(std::lower_bound(W.need.begin(), W.need.end(), rec) - W.need.begin());
+        return W.got[which][slot];
+    };
+
+    // ---- phase 2: interval tree, overlap groups, the six point sets (:215-347), per contig ---------------------------------------
+    parallel_over(contigs.size(), params.threads, [&](size_t k) {
+        ContigWork &W = work[by_size[k]];
+        const SplitContig &C = *W.in;
+        const int primary_tid = C.tid;
+        W.member.reserve(W.member_rec.size());
+        W.member_supps.resize(W.member_rec.size());
+        for (size_t m = 0; m < W.member_rec.size(); m++) {
+            const uint32_t i = W.member_rec[m];
+            W.member.push_back(PrimaryAlignment{C.pos[i] + 1, interval(W, i, 0), interval(W, i, 1), interval(W, i, 2), !(C.flag[i] & FLAG_REVERSE), 0});
+            for (size_t q = m ? W.member_supp_off[m - 1] : 0; q < W.member_supp_off[m]; q++) {
+                const ContigWork &SW = work[W.member_supp_ref[q].first];
+                const SplitContig &S = *SW.in;
+                const uint32_t r = W.member_supp_ref[q].second;
+                W.member_supps[m].push_back(SuppAlignment{S.tid, S.pos[r] + 1, interval(SW, r, 0), interval(SW, r, 1), interval(SW, r, 2), !(S.flag[r] & FLAG_REVERSE)});
+            }
+        }
 
         // overlap groups (:215-238): direct overlaps of the first unprocessed read in iteration order, not transitive
         IntervalTree tree;

@@ -36,6 +36,14 @@ struct SplitParams {
     int threads = 0;          // host threads over contigs (0: one per contig, at most the hardware's); the result does not depend on it
 };
 
+// Where the scan kernel's per-record intervals come from when they are not handed over as whole arrays: only the records that take
+// part in a group (primaries with a supplementary record, and those records) are ever asked for — a few per cent of a contig.
+struct IntervalSource {
+    virtual ~IntervalSource() = default;
+    // ref_end / q_start / q_end of records rec[0..n) (ascending, distinct)
+    virtual void gather(const uint32_t *rec, size_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end) const = 0;
+};
+
 // The records of one contig (one tid), struct of arrays, file order — what a decoded shard holds on the host plus the scan
 // kernel's intervals. Query names are needed for two things only: their std::hash<std::string> value (qhash: it fixes where the
 // reference's unordered_map puts a read, see umap_order.h) and equality. Equality comes from the names themselves (name_bytes /
@@ -46,7 +54,8 @@ struct SplitContig {
     const int32_t *pos = nullptr;
     const uint16_t *flag = nullptr;
     const uint8_t *mapq = nullptr;
-    const int32_t *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr;
+    const int32_t *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr;   // whole arrays, or ...
+    const IntervalSource *intervals = nullptr;                               // ... a source asked for the few records that matter
     const uint64_t *qhash = nullptr;
     const uint64_t *name_id = nullptr;
     const char *name_bytes = nullptr;

@@ -315,6 +315,17 @@ void SVCaller::processChromosome(const std::string &chr, const csv_reads &reads,
 
 
 namespace {
+// alignment intervals of selected records of a resident shard (csvgpu_aln_intervals_gather_resident)
+struct ShardIntervals : IntervalSource {
+    ShardIntervals(csv_ctx *ctx, csv_shard *shard) : ctx(ctx), shard(shard) {}
+    void gather(const uint32_t *rec, size_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end) const override
+    {
+        check(ctx, csvgpu_aln_intervals_gather_resident(ctx, shard, rec, n, ref_end, q_start, q_end), "alignment intervals");
+    }
+    csv_ctx *ctx;
+    csv_shard *shard;
+};
+
 struct EmptySnps : SNPSource {
     void query(uint32_t, uint32_t, std::vector<uint32_t> &, std::unordered_map<uint32_t, double> &, std::unordered_map<uint32_t, double> &) const override {}
 };
@@ -453,7 +464,7 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
     std::vector<std::string> names;
     for (size_t i = 0; i < contigs.size(); i++) { index_of[contigs[i].name] = i; names.push_back(contigs[i].name); }
     CNVCaller cnv(ctx);
-    cnv.sample_size = P.sample_size; cnv.min_cnv_length = P.min_cnv_length;
+    cnv.sample_size = P.sample_size; cnv.min_cnv_length = P.min_cnv_length; cnv.host_threads = P.host_threads;
     if (P.save_cnv && !P.vcf.output_dir.empty()) {                                 // main.cpp:109-118
         cnv.save_cnv_data = true;
         cnv.cnv_output_file = P.vcf.output_dir + "/CNVCalls.json";
@@ -461,29 +472,37 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         printMessage("Saving CNV data to: " + cnv.cnv_output_file);
     }
     double t0 = now_ms();
-    if (P.cigar_svs && P.cigar_cn) {                                               // :865-881
-        printMessage("Running copy number predictions on CIGAR SVs...");
-        for (auto &entry : whole_genome_sv_calls) {
+    auto cn_jobs = [&](std::unordered_map<std::string, std::vector<SVCall>> &m) {
+        std::vector<CNVCaller::ContigJob> jobs;
+        for (auto &entry : m) {                                                      // the map's own order, as the reference walks it
             if (entry.second.empty()) continue;
             const size_t i = index_of.at(entry.first);
-            T.n_cigar_cn_regions += cnv.runCIGARCopyNumberPrediction(entry.first, entry.second, hmm, stats[i].mean_chr_cov, contigs[i].shard,
-                                                                     contigs[i].snps ? *contigs[i].snps : (const SNPSource &)no_snps);
+            CNVCaller::ContigJob j;
+            j.chr = entry.first; j.calls = &entry.second; j.mean_chr_cov = stats[i].mean_chr_cov; j.shard = contigs[i].shard;
+            j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
+            jobs.push_back(j);
         }
+        return jobs;
+    };
+    if (P.cigar_svs && P.cigar_cn) {                                               // :865-881
+        printMessage("Running copy number predictions on CIGAR SVs...");
+        std::vector<CNVCaller::ContigJob> jobs = cn_jobs(whole_genome_sv_calls);
+        T.n_cigar_cn_regions += cnv.runCIGARCopyNumberPredictionAll(jobs, hmm);
     }
     T.ms_cigar_cn = now_ms() - t0;
     if (P.split_svs) {                                                             // :885-917
         t0 = now_ms();
-        // the scan kernel's per-read intervals (the reference's third BAM pass, :137-172) come back from the shards
-        std::vector<std::vector<int32_t>> iv(contigs.size() * 3);
+        // the scan kernel's per-read intervals (the reference's third BAM pass, :137-172) stay in the shards: the pass gathers the
+        // few records it needs (ShardIntervals)
+        std::vector<std::unique_ptr<ShardIntervals>> sources;
         std::vector<SplitContig> blocks;
         for (size_t i = 0; i < contigs.size(); i++) {
             ResidentContig &c = contigs[i];
             if (!c.split.qhash || !c.shard || !c.split.n) continue;
-            const uint64_t n = c.split.n;
-            for (int k = 0; k < 3; k++) iv[i * 3 + (size_t)k].resize(n);
-            check(ctx, csvgpu_aln_intervals_resident(ctx, c.shard, iv[i * 3].data(), iv[i * 3 + 1].data(), iv[i * 3 + 2].data()), "alignment intervals");
+            sources.emplace_back(new ShardIntervals(ctx, c.shard));
             c.split.tid = (int32_t)i;
-            c.split.ref_end = iv[i * 3].data(); c.split.q_start = iv[i * 3 + 1].data(); c.split.q_end = iv[i * 3 + 2].data();
+            c.split.ref_end = c.split.q_start = c.split.q_end = nullptr;
+            c.split.intervals = sources.back().get();
             blocks.push_back(c.split);
         }
         T.ms_split_fetch = now_ms() - t0;
@@ -493,15 +512,17 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         findSplitSVSignatures(blocks, names, sp, split_calls);
         T.ms_split = now_ms() - t0;
         t0 = now_ms();
-        for (auto &entry : split_calls) {
-            if (entry.second.empty()) continue;
-            const size_t i = index_of.at(entry.first);
-            cnv.runSplitReadCopyNumberPredictions(entry.first, entry.second, hmm, stats[i].mean_chr_cov, contigs[i].shard,
-                                                  contigs[i].snps ? *contigs[i].snps : (const SNPSource &)no_snps, contigs[i].depth_len);
+        {
+            std::vector<CNVCaller::ContigJob> jobs = cn_jobs(split_calls);
+            cnv.runSplitReadCopyNumberPredictionsAll(jobs, hmm);
         }
         T.ms_split_cn = now_ms() - t0;
         t0 = now_ms();
-        if (P.merge_split_svs) for (auto &entry : split_calls) mergeSVs(entry.second, 0.1, 2, true);
+        if (P.merge_split_svs) {
+            std::vector<std::vector<SVCall> *> sets;
+            for (auto &entry : split_calls) sets.push_back(&entry.second);
+            mergeSVsMany(sets, 0.1, 2, true, P.host_threads);
+        }
         for (auto &entry : split_calls) {
             T.n_split_calls += entry.second.size();
             std::vector<SVCall> &dst = whole_genome_sv_calls[entry.first];
@@ -510,7 +531,11 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         T.ms_merge_split = now_ms() - t0;
     }
     t0 = now_ms();
-    if (P.merge_final_svs) for (auto &entry : whole_genome_sv_calls) mergeSVs(entry.second, 0.1, 2, true);   // :919-927
+    if (P.merge_final_svs) {                                                                                 // :919-927
+        std::vector<std::vector<SVCall> *> sets;
+        for (auto &entry : whole_genome_sv_calls) sets.push_back(&entry.second);
+        mergeSVsMany(sets, 0.1, 2, true, P.host_threads);
+    }
     T.ms_merge_final = now_ms() - t0;
     if (cnv.save_cnv_data) CNVCaller::closeJSON(cnv.cnv_output_file);                                       // :929-931
     uint32_t total = 0;

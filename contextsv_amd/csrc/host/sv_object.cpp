@@ -8,6 +8,7 @@
 
 #include "dbscan.h"
 #include "log.h"
+#include "par.h"
 
 // sorted insert by (start,end); an element equal to existing ones goes BEFORE them (std::lower_bound),
 // which is what fixes DBSCAN's index order (reference sv_object.cpp:22-33)
@@ -104,6 +105,34 @@ void mergeSVs(std::vector<SVCall> &sv_calls, double epsilon, int min_pts, bool k
     }
     sv_calls = std::move(merged);
     printMessage("Merged " + std::to_string(initial) + " SV calls into " + std::to_string(sv_calls.size()) + " SV calls");
+}
+
+void mergeSVsMany(const std::vector<std::vector<SVCall> *> &sets, double epsilon, int min_pts, bool keep_noise, int threads)
+{
+    static const SVType kTypes[5] = {SVType::DEL, SVType::DUP, SVType::INV, SVType::INS, SVType::BND};   // sv_object.cpp:62-68
+    const size_t n = sets.size();
+    std::vector<std::vector<SVCall>> type_calls(n * 5);
+    csvhost::parallel_for(n, threads, [&](size_t k) {
+        if (sets[k]->size() < 2) return;                                      // mergeSVs returns early (:49-51)
+        for (int t = 0; t < 5; t++)
+            for (const SVCall &c : *sets[k]) if (c.sv_type == kTypes[t]) type_calls[k * 5 + (size_t)t].push_back(c);
+    });
+    std::vector<const std::vector<SVCall> *> fits;
+    std::vector<size_t> fit_of(n * 5, SIZE_MAX);
+    for (size_t q = 0; q < n * 5; q++) if (type_calls[q].size() >= 2) { fit_of[q] = fits.size(); fits.push_back(&type_calls[q]); }
+    std::vector<std::vector<int>> labels;
+    DBSCAN::fitBatch(fits, epsilon, min_pts, labels);
+    csvhost::parallel_for(n, threads, [&](size_t k) {
+        if (sets[k]->size() < 2) return;
+        std::vector<SVCall> merged;
+        for (int t = 0; t < 5; t++) {
+            std::vector<SVCall> &tc = type_calls[k * 5 + (size_t)t];
+            if (tc.size() < 2) { merged.insert(merged.end(), tc.begin(), tc.end()); continue; }    // passes through untouched (:85-92)
+            mergeTypeWithLabels(tc, labels[fit_of[k * 5 + (size_t)t]].data(), keep_noise, merged);
+        }
+        *sets[k] = std::move(merged);
+    });
+    printMessage("Merged " + std::to_string(n) + " call sets with DBSCAN, eps=" + std::to_string(epsilon) + ", min_pts=" + std::to_string(min_pts));
 }
 
 // equal (start,end) neighbours after a (start, sv_type) sort collapse into the later one with summed

@@ -39,6 +39,10 @@ uint32_t getSVCount(const std::vector<SVCall> &sv_calls);
 void concatenateSVCalls(std::vector<SVCall> &target, const std::vector<SVCall> &source);
 void mergeSVs(std::vector<SVCall> &sv_calls, double epsilon, int min_pts, bool keep_noise, const std::string &json_filepath = "");
 
+// mergeSVs on many call vectors at once (the final merges of a run, one vector per contig): every (vector, type) set of two or more
+// calls goes through ONE batched device fit, the representative choices run on the host pool. Same result as mergeSVs on each.
+void mergeSVsMany(const std::vector<std::vector<SVCall> *> &sets, double epsilon, int min_pts, bool keep_noise, int threads = 0);
+
 // The part of mergeSVs after DBSCAN::fit: `type_calls` are the calls of one SV type in vector order and
 // `labels` their cluster labels; appends the representatives to `merged` (sv_object.cpp:97-264 of the reference).
 // Exposed so the per-chromosome pipeline can feed labels that are already on hand from the device pipeline.

@@ -26,6 +26,7 @@ class UMapOrder {
 public:
     UMapOrder() : bkt_(1, kEmpty) {}
     void reserve(size_t n) { hash_.reserve(n); next_.reserve(n); }
+    void clear() { hash_.clear(); next_.clear(); bkt_.assign(1, kEmpty); head_ = -1; n_bkt_ = 1; policy_ = std::__detail::_Prime_rehash_policy(); }
     size_t size() const { return hash_.size(); }
 
     // operator[] / find: the node holding the key with hash h for which same(node) is true, or -1. same() is only asked about

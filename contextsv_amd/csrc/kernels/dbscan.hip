@@ -439,4 +439,96 @@ void launch_dbscan_1d_big(hipStream_t s, const int32_t *pts_sorted, const uint32
     run_dbscan(s, m, oid, n, n, min_pts, nullptr, labels, tmp);
 }
 
+// ---- many small interval sets in ONE launch (the final mergeSVs of a run: one set per (contig, SV type), a few hundred to a few
+// thousand calls each, in the caller's — not start-sorted — order) --------------------------------------------------------------------
+// One workgroup per set, everything in LDS, brute force over all pairs with the reference's predicate: core flags, union-find of the
+// core points (larger root under smaller: a component's root is its smallest original index = its start point), start points ranked
+// in index order, then the border rule. Same order-free labelling as the windowed kernels above; no sort, no scratch in HBM.
+constexpr int IVS_THREADS = 256;
+constexpr int IVS_MAX = (int)DBSCAN_IV_SMALL_MAX;
+
+__global__ __launch_bounds__(IVS_THREADS) void dbscan_iv_small_kernel(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end,
+                                                                     const uint64_t *__restrict__ seg_off, uint64_t n_seg, double eps, int min_pts,
+                                                                     int32_t *__restrict__ labels)
+{
+    __shared__ uint32_t ls[IVS_MAX], le[IVS_MAX], lpar[IVS_MAX], lcid[IVS_MAX + 1];
+    __shared__ uint8_t lcore[IVS_MAX];
+    __shared__ uint32_t wave_tot[IVS_THREADS / WAVE];
+    for (uint64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const uint64_t o0 = seg_off[seg];
+        const uint64_t n64 = seg_off[seg + 1] - o0;
+        if (n64 == 0 || n64 > (uint64_t)IVS_MAX) continue;           // larger sets: the windowed path (host decides)
+        const int n = (int)n64;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += IVS_THREADS) { ls[i] = start[o0 + i]; le[i] = end[o0 + i]; lpar[i] = (uint32_t)i; }
+        __syncthreads();
+        // core points: |N(i)| >= min_pts, N(i) = { j : distance(i, j) <= eps } (regionQuery, dbscan.cpp:59-67; includes i itself)
+        for (int i = threadIdx.x; i < n; i += IVS_THREADS) {
+            const uint32_t si = ls[i], ei = le[i];
+            int cnt = 0;
+            for (int j = 0; j < n; j++) cnt += iv_neighbor(si, ei, ls[j], le[j], eps);
+            lcore[i] = cnt >= min_pts;
+        }
+        __syncthreads();
+        // components of the core points
+        for (int i = threadIdx.x; i < n; i += IVS_THREADS) {
+            if (!lcore[i]) continue;
+            const uint32_t si = ls[i], ei = le[i];
+            for (int j = i + 1; j < n; j++) {
+                if (!lcore[j] || !iv_neighbor(si, ei, ls[j], le[j], eps)) continue;
+                uint32_t a = (uint32_t)i, b = (uint32_t)j;
+                for (;;) {
+                    a = lds_find(lpar, a); b = lds_find(lpar, b);
+                    if (a == b) break;
+                    if (a > b) { const uint32_t t = a; a = b; b = t; }
+                    if (atomicCAS(&lpar[b], b, a) == b) break;
+                }
+            }
+        }
+        __syncthreads();
+        // start points (roots) ranked in index order: exclusive prefix sum of the root flags
+        uint32_t carry = 0;
+        for (int i0 = 0; i0 < n; i0 += IVS_THREADS) {
+            const int i = i0 + (int)threadIdx.x;
+            const uint32_t v = (i < n && lcore[i] && lds_ld(&lpar[i]) == (uint32_t)i) ? 1u : 0u;
+            const uint32_t incl = wave_incl_sum(v);
+            if (lane_id() == 63) wave_tot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t before = carry;
+            for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wave_tot[w];
+            if (i < n) lcid[i] = before + incl - v;
+            uint32_t tot = 0;
+            for (int w = 0; w < IVS_THREADS / WAVE; w++) tot += wave_tot[w];
+            carry += tot;
+            __syncthreads();
+        }
+        // labels
+        for (int i = threadIdx.x; i < n; i += IVS_THREADS) {
+            int32_t lab;
+            if (lcore[i]) {
+                lab = (int32_t)lcid[lds_find(lpar, (uint32_t)i)];
+            } else {
+                const uint32_t si = ls[i], ei = le[i];
+                int32_t max_start = -1, min_core = INT32_MAX;
+                for (int j = 0; j < n; j++) {
+                    if (!lcore[j] || !iv_neighbor(si, ei, ls[j], le[j], eps)) continue;
+                    const uint32_t rj = lds_find(lpar, (uint32_t)j);
+                    const int32_t c = (int32_t)lcid[rj];
+                    if (rj == (uint32_t)j) max_start = max(max_start, c); else min_core = min(min_core, c);
+                }
+                lab = max_start >= 0 ? max_start : (min_core != INT32_MAX ? min_core : -2);
+            }
+            labels[o0 + i] = lab;
+        }
+    }
+}
+
+void launch_dbscan_iv_small_batched(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint64_t *seg_off, uint64_t n_seg, double eps,
+                                    int min_pts, int32_t *labels)
+{
+    if (n_seg == 0) return;
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_seg, 8192);
+    hipLaunchKernelGGL(dbscan_iv_small_kernel, dim3(grid), dim3(IVS_THREADS), 0, s, start, end, seg_off, n_seg, eps, min_pts, labels);
+}
+
 }  // namespace csv

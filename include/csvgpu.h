@@ -162,6 +162,13 @@ int csvgpu_depth(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len,
 int csvgpu_dbscan_iv(csv_ctx *ctx, const uint32_t *start, const uint32_t *end, uint64_t n,
                      double eps, int32_t min_pts, int32_t *labels);
 
+/* DBSCAN::fit for a batch of independent interval sets in one call — the per-type fits of mergeSVs (sv_object.cpp:62-94) for every
+ * contig of a run at once (the two final merges, sv_caller.cpp:907, :925): set s = intervals [seg_off[s], seg_off[s+1]) in CALLER
+ * order, labels per set exactly as csvgpu_dbscan_iv gives them. Sets of up to 2048 intervals share one launch (one workgroup each,
+ * all pairs in LDS); larger ones take the windowed path one by one. */
+int csvgpu_dbscan_iv_batch(csv_ctx *ctx, const uint32_t *start, const uint32_t *end, const uint64_t *seg_off, uint64_t n_seg,
+                           double eps, int32_t min_pts, int32_t *labels);
+
 /* Replaces DBSCAN1D::fit + getClusters for a batch of independent point sets
  * (dbscan1d.cpp:8-70; the six fits per overlap group of sv_caller.cpp:270-372 become one call):
  * segment s = pts[seg_off[s] .. seg_off[s+1]); labels in caller order per segment. Metric
@@ -278,6 +285,10 @@ void csvgpu_host_free(csv_ctx *ctx, void *p);
 
 /* The alignment intervals that the last csvgpu_chr_pipeline_dev() computed for every record of `shard`, copied to host. */
 int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *shard, int32_t *ref_end, int32_t *q_start, int32_t *q_end);
+
+/* The same for selected records only: ref_end[i] / q_start[i] / q_end[i] of record rec[i] (the split-read pass needs the intervals of
+ * the primaries that have a supplementary record and of those records — a few per cent of a contig; sv_caller.cpp:152, :162). */
+int csvgpu_aln_intervals_gather_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *rec, uint64_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end);
 
 /* csvgpu_window_log2 on the depth map that the last csvgpu_chr_pipeline_dev() left resident in `shard`
  * (region tables and outputs are host memory; the depth map never leaves HBM). */

@@ -41,3 +41,27 @@ def test_dbscan1d_vs_reference_code(ctx, ref):
         min_pts = int(rng.choice([1, 2, 5, 6]))
         got = ctx.dbscan_1d(p, np.array([0, n], np.uint64), eps, min_pts)
         assert np.array_equal(got, ref.dbscan_1d(p, eps, min_pts)), (it, n, eps, min_pts)
+
+
+def test_interval_dbscan_batch_against_reference(ctx, ref):
+    """csvgpu_dbscan_iv_batch (one workgroup per set, all pairs in LDS, caller order) against the reference's own dbscan.cpp set by
+    set: unsorted starts, duplicates, zero-length and nested intervals, every min_pts the path uses, set sizes on both sides of the
+    2048-point limit of the LDS kernel (larger sets take the windowed path), empty sets in between."""
+    rng = np.random.default_rng(77)
+    sets = []
+    for n in [0, 1, 2, 3, 17, 64, 65, 300, 1000, 2047, 2048, 2049, 3000, 0, 5]:
+        centres = rng.integers(1000, 200_000, max(1, n // 7 + 1))
+        c = centres[rng.integers(0, len(centres), n)]
+        length = rng.choice([0, 1, 49, 50, 300, 2000, 40_000], n, p=[.02, .02, .06, .3, .3, .2, .1])
+        jit = rng.integers(-8, 9, n)
+        s = np.maximum(1, c + jit).astype(np.uint32)
+        e = (s + np.maximum(0, length + rng.integers(-3, 4, n))).astype(np.uint32)
+        sets.append((s, e))
+    off = np.zeros(len(sets) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s, _ in sets])
+    S = np.concatenate([s for s, _ in sets]); E = np.concatenate([e for _, e in sets])
+    for eps, min_pts in ((0.1, 2), (0.1, 3), (0.3, 5), (0.0, 1)):
+        got = ctx.dbscan_iv_batch(S, E, off, eps, min_pts)
+        for k, (s, e) in enumerate(sets):
+            exp = ref.dbscan_iv(s, e, eps, min_pts)
+            assert np.array_equal(got[int(off[k]): int(off[k + 1])], exp), (k, len(s), eps, min_pts)
