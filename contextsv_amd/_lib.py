@@ -17,8 +17,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcsvgpu.so")
 CSV_OK, CSV_EINVAL, CSV_ENODEV, CSV_ENOMEM, CSV_EHIP, CSV_ECAPACITY = 0, -1, -2, -3, -4, -5
 STATUS_NAMES = {0: "CSV_OK", -1: "CSV_EINVAL", -2: "CSV_ENODEV", -3: "CSV_ENOMEM", -4: "CSV_EHIP", -5: "CSV_ECAPACITY"}
 
-K_CIGAR_SCAN, K_DEPTH, K_SORT, K_DBSCAN, K_DBSCAN1D, K_WINDOW, K_VITERBI, K_MISC, K_COUNT = range(9)
-KERNEL_NAMES = ["cigar_scan", "depth", "sort", "dbscan", "dbscan1d", "window", "viterbi", "misc"]
+K_CIGAR_SCAN, K_DEPTH, K_SORT, K_DBSCAN, K_DBSCAN1D, K_WINDOW, K_VITERBI, K_MISC, K_SPLIT_ORDER, K_COUNT = range(10)
+KERNEL_NAMES = ["cigar_scan", "depth", "sort", "dbscan", "dbscan1d", "window", "viterbi", "misc", "split_order"]
 
 SIG_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("read", "<u4"), ("qpos_kind", "<u4")])
 KIND_INS, KIND_DEL, KIND_CLIP = 0, 1, 2
@@ -83,6 +83,8 @@ ABI = {
     "csvgpu_host_free": (None, [_P, _P]),
     "csvgpu_aln_intervals_resident": (C.c_int, [_P, _P, _P, _P, _P]),
     "csvgpu_aln_intervals_gather_resident": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P]),
+    "csvgpu_shard_set_qname_hash": (C.c_int, [_P, _P, _P]),
+    "csvgpu_split_order": (C.c_int, [_P, C.c_int, _P, C.c_uint8, _P, C.c_uint64, _P, C.c_uint64, _P]),
     "csvgpu_window_log2_resident": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_double, _P, _P, _P]),
     "csvgpu_chr_fetch": (C.c_int, [_P, _P, C.POINTER(csv_chr_result), _P, _P]),
     "csvgpu_depth_lookup_resident": (C.c_int, [_P, _P, _P, C.c_uint64, _P]),

@@ -178,6 +178,21 @@ class Context:
         self._check(self.lib.csvgpu_viterbi(self.h, C.byref(hmm), ptr(o1), ptr(o2), ptr(pfb), ptr(seq_off), n_seq, ptr(states), ptr(ll)))
         return states[: len(o1)], ll[:n_seq]
 
+    def split_order(self, shards, min_mapq: int, supp_hash, capacity: int | None = None):
+        """csvgpu_split_order: per contig (shard with query-name hashes attached) the records of the surviving primaries in the
+        iteration order of the reference's qname map -> list of uint32 arrays."""
+        supp_hash = np.ascontiguousarray(supp_hash, np.uint64)
+        n = len(shards)
+        hs = (C.c_void_p * max(n, 1))(*[s.h for s in shards])
+        cap = capacity if capacity is not None else max(1024, 2 * len(supp_hash))
+        out = np.zeros(max(cap, 1), np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        rc = self.lib.csvgpu_split_order(self.h, n, hs, min_mapq, ptr(supp_hash), len(supp_hash), ptr(out), cap, ptr(off))
+        if rc == _lib.CSV_ECAPACITY and capacity is None:
+            return self.split_order(shards, min_mapq, supp_hash, capacity=int(off[n]))
+        self._check(rc)
+        return [out[int(off[k]): int(off[k + 1])].copy() for k in range(n)]
+
     # -------------------------------------------------------------------------------- timing
     def synchronize(self):
         self._check(self.lib.csvgpu_synchronize(self.h))
@@ -252,6 +267,11 @@ class Shard:
         if self.h and self.ctx.h:
             self.ctx.lib.csvgpu_shard_free(self.ctx.h, self.h)
         self.h = None
+
+    def set_qname_hash(self, qhash):
+        qhash = np.ascontiguousarray(qhash, np.uint64)
+        assert len(qhash) == self.n_reads
+        self.ctx._check(self.ctx.lib.csvgpu_shard_set_qname_hash(self.ctx.h, self.h, ptr(qhash)))
 
     def pipeline(self, eps: float = 0.1, min_pts_pct: float = 0.1, min_oplen: int = 50, min_mapq: int = 20) -> ChrResult:
         res = csv_chr_result()

@@ -86,6 +86,7 @@ struct csv_shard {
     char     *scratch = nullptr;   size_t scratch_cap = 0;   // sort / dbscan workspace
     uint64_t *counters = nullptr;  // device scalars (see ScanCounters) + bucket tables + the depth tiles' candidate ranges, zeroed together per chromosome
     uint64_t *tile_range = nullptr;   // inside `counters`
+    uint64_t *qhash = nullptr;        // [n_reads] std::hash<std::string> of every record's query name (csvgpu_shard_set_qname_hash), or null
     size_t    counters_bytes = 0;
 };
 
@@ -208,6 +209,28 @@ void launch_dbscan_iv_sorted(hipStream_t s, const uint32_t *start, const uint32_
 constexpr uint32_t DBSCAN_IV_SMALL_MAX = 2048;
 void launch_dbscan_iv_small_batched(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint64_t *seg_off, uint64_t n_seg, double eps,
                                     int min_pts, int32_t *labels);
+// splitorder.hip — the node order of the reference's per-chromosome qname hash map, all contigs of a batch per launch
+constexpr uint32_t SO_MAX_CONTIGS = 32;
+struct SplitOrderTab {                       // passed to the kernels by value
+    uint32_t A = 0;                          // contigs in this table
+    uint64_t blk_off[SO_MAX_CONTIGS + 1];    // compaction: first 1024-record block of each contig
+    uint64_t work_off[SO_MAX_CONTIGS + 1];   // epoch: first work item (node present in the epoch) of each active contig
+    uint32_t nbase[SO_MAX_CONTIGS + 1];      // global index of each contig's first node
+    uint64_t n_reads[SO_MAX_CONTIGS];
+    const uint16_t *flag[SO_MAX_CONTIGS];
+    const uint8_t *mapq[SO_MAX_CONTIGS];
+    const uint64_t *qhash[SO_MAX_CONTIGS];
+};
+struct csv_split_survivor { uint32_t contig, pos, rec; };
+void launch_so_count(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, uint32_t *blk_cnt);
+void launch_so_scatter(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, const uint32_t *blk_off, uint64_t *node_hash,
+                       uint32_t *node_rec, uint32_t *pos);
+void launch_so_mint(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, const uint64_t *node_hash, const uint32_t *pos, uint32_t *minT);
+void launch_so_keys(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, int w, const uint64_t *node_hash, const uint32_t *pos,
+                    const uint32_t *minT, uint64_t *keys, uint32_t *vals);
+void launch_so_setpos(hipStream_t s, const SplitOrderTab &tab, uint64_t M, const uint32_t *vals, uint32_t *pos);
+void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nodes, const uint64_t *node_hash, const uint32_t *node_rec, const uint32_t *pos,
+                         const uint64_t *supp_hash, uint64_t n_supp, csv_split_survivor *out, uint64_t cap, unsigned long long *count);
 // dbscan1d.hip
 void launch_dbscan_1d_batched(hipStream_t s, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg,
                               double eps, int min_pts, int32_t *labels, unsigned int *too_large_flag);

@@ -7,6 +7,7 @@
 
 #include "common.hpp"
 #include <chrono>
+#include <unordered_map>
 
 namespace csv {
 
@@ -790,6 +791,7 @@ static void shard_release(csv_shard *sh)
     }
     (void)hipFree(sh->ref_end); (void)hipFree(sh->q_start); (void)hipFree(sh->q_end);
     (void)hipFree(sh->ckpt);
+    (void)hipFree(sh->qhash);
     (void)hipFree(sh->depth); (void)hipFree(sh->sig_raw); (void)hipFree(sh->scratch); (void)hipFree(sh->counters);
     delete sh;
 }
@@ -899,6 +901,160 @@ int csvgpu_aln_intervals_gather_resident(csv_ctx *ctx, csv_shard *sh, const uint
         CSV_HIP(ctx, hipMemcpyAsync(dst[k], dout[k], n * 4, hipMemcpyDeviceToHost, s));
     }
     CSV_HIP(ctx, hipStreamSynchronize(s));
+    return CSV_OK;
+}
+
+int csvgpu_shard_set_qname_hash(csv_ctx *ctx, csv_shard *sh, const uint64_t *qname_hash)
+{
+    if (!ctx || !sh) return CSV_EINVAL;
+    const uint64_t n = sh->d.n_reads;
+    if (n && !qname_hash) { ctx->err = "set_qname_hash: null array"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    if (!sh->qhash) {
+        if (hipMalloc((void **)&sh->qhash, n * 8 + 16) != hipSuccess) { (void)hipGetLastError(); sh->qhash = nullptr; ctx->err = "hipMalloc failed (qname hashes)"; return CSV_ENOMEM; }
+    }
+    if (n) CSV_HIP(ctx, hipMemcpyAsync(sh->qhash, qname_hash, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CSV_OK;
+}
+
+// the epochs of a libstdc++ hash table that grows by single insertions: node index at which each rehash happens, and the bucket
+// count from there on — asked of the library's own policy object (what std::unordered_map itself consults)
+static void split_order_epochs(uint64_t n_max, std::vector<uint64_t> &first_node, std::vector<uint64_t> &buckets)
+{
+    static std::mutex mu;
+    static std::vector<uint64_t> c_first, c_bkt;
+    static uint64_t covered = 0;                              // the plan is known for tables of up to `covered` nodes
+    std::lock_guard<std::mutex> l(mu);
+    if (n_max > covered) {
+        c_first.clear(); c_bkt.clear();
+        std::__detail::_Prime_rehash_policy pol;
+        std::size_t nb = 1;
+        const uint64_t want = std::max<uint64_t>(n_max, 1u << 20);
+        for (uint64_t i = 0; i < want;) {
+            const std::pair<bool, std::size_t> g = pol._M_need_rehash(nb, i, 1);
+            if (g.first) { nb = g.second; c_first.push_back(i); c_bkt.push_back(nb); }
+            // nothing can happen before the table is full again (max_load_factor 1): jump there
+            i = (g.first || i + 1 >= nb) ? i + 1 : std::min<uint64_t>(want, (uint64_t)nb);
+        }
+        covered = want;
+    }
+    first_node = c_first; buckets = c_bkt;
+}
+
+int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq, const uint64_t *supp_hash, uint64_t n_supp,
+                       uint32_t *out_rec, uint64_t capacity, uint64_t *out_off)
+{
+    if (!ctx) return CSV_EINVAL;
+    if (n_contigs < 0 || (uint32_t)n_contigs > SO_MAX_CONTIGS) { ctx->err = "split_order: at most 32 contigs per call"; return CSV_EINVAL; }
+    if (!out_off || (n_contigs && !shards) || (n_supp && !supp_hash) || (capacity && !out_rec)) { ctx->err = "split_order: null array"; return CSV_EINVAL; }
+    for (int c = 0; c <= n_contigs; c++) out_off[c] = 0;
+    if (n_contigs == 0) return CSV_OK;
+    for (uint64_t i = 1; i < n_supp; i++) if (supp_hash[i] <= supp_hash[i - 1]) { ctx->err = "split_order: supp_hash must be sorted and distinct"; return CSV_EINVAL; }
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    SplitOrderTab tab;
+    tab.A = (uint32_t)n_contigs;
+    uint64_t total_reads = 0, n_blocks = 0;
+    for (int c = 0; c < n_contigs; c++) {
+        const csv_shard *sh = shards[c];
+        if (!sh || (sh->d.n_reads && !sh->qhash)) { ctx->err = "split_order: a shard without query-name hashes (csvgpu_shard_set_qname_hash)"; return CSV_EINVAL; }
+        tab.blk_off[c] = n_blocks;
+        tab.n_reads[c] = sh->d.n_reads; tab.flag[c] = sh->d.flag; tab.mapq[c] = sh->d.mapq; tab.qhash[c] = sh->qhash;
+        n_blocks += (sh->d.n_reads + 1023) / 1024;
+        total_reads += sh->d.n_reads;
+    }
+    tab.blk_off[n_contigs] = n_blocks;
+    if (total_reads == 0 || n_supp == 0) return CSV_OK;
+    if (total_reads >= 0xfffffff0ull) { ctx->err = "split_order: too many records in one call"; return CSV_EINVAL; }
+    TimerScope ts(ctx, CSV_K_SPLIT_ORDER);
+
+    // ---- nodes: the filter-passing primaries of every contig, file order ----
+    int rc = arena_reserve(ctx, ctx->arena, align_up((n_blocks + 1) * 4, 256) + exclusive_sum_tmp_bytes(n_blocks + 1) + align_up(total_reads * 8, 256) +
+                                                2 * align_up(total_reads * 4, 256) + align_up(n_supp * 8, 256) + 4096);
+    if (rc) return rc;
+    uint32_t *blk = (uint32_t *)arena_alloc(ctx->arena, (n_blocks + 1) * 4);
+    void *es_tmp = arena_alloc(ctx->arena, exclusive_sum_tmp_bytes(n_blocks + 1));
+    uint64_t *node_hash = (uint64_t *)arena_alloc(ctx->arena, total_reads * 8);
+    uint32_t *node_rec = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4), *pos = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4);
+    uint64_t *d_supp = (uint64_t *)arena_alloc(ctx->arena, n_supp * 8);
+    if (!blk || !es_tmp || !node_hash || !node_rec || !pos || !d_supp) { ctx->err = "arena exhausted (split order)"; return CSV_ENOMEM; }
+    CSV_HIP(ctx, hipMemcpyAsync(d_supp, supp_hash, n_supp * 8, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemsetAsync(blk + n_blocks, 0, 4, s));
+    launch_so_count(s, tab, (uint32_t)n_blocks, min_mapq, blk);
+    launch_exclusive_sum_u32(s, blk, n_blocks + 1, es_tmp);
+    launch_so_scatter(s, tab, (uint32_t)n_blocks, min_mapq, blk, node_hash, node_rec, pos);
+    if ((rc = ensure_pinned(ctx, (n_blocks + 1) * 4 + 64))) return rc;
+    CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, blk, (n_blocks + 1) * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, wait_stream(s));
+    const uint32_t *h_blk = (const uint32_t *)ctx->pinned;
+    std::vector<uint64_t> N((size_t)n_contigs);
+    uint64_t n_nodes = h_blk[n_blocks], n_max = 0;
+    for (int c = 0; c < n_contigs; c++) {
+        tab.nbase[c] = h_blk[tab.blk_off[c]];
+        N[(size_t)c] = (uint64_t)h_blk[tab.blk_off[c + 1]] - h_blk[tab.blk_off[c]];
+        n_max = std::max(n_max, N[(size_t)c]);
+    }
+    tab.nbase[n_contigs] = (uint32_t)n_nodes;
+    if (n_nodes == 0) return CSV_OK;
+
+    // ---- the chain of epochs: a contig takes part in epoch k while it still has nodes inserted at or after the epoch's first node ----
+    std::vector<uint64_t> first_node, buckets;
+    split_order_epochs(n_max, first_node, buckets);
+    uint64_t scratch = 0;
+    for (size_t k = 0; k < first_node.size(); k++) {
+        uint64_t A = 0;
+        for (int c = 0; c < n_contigs; c++) A += N[(size_t)c] > first_node[k];
+        scratch = std::max(scratch, A * buckets[k] * 4);
+    }
+    if ((rc = arena_reserve(ctx, ctx->work, align_up(scratch, 256) + sortws_bytes(n_nodes) + align_up(n_nodes * sizeof(csv_split_survivor), 256) + 4096))) return rc;
+    uint32_t *minT = (uint32_t *)arena_alloc(ctx->work, scratch + 16);
+    SortWs w;
+    if (!minT || !sortws_carve(ctx->work, n_nodes, w)) { ctx->err = "arena exhausted (split order epochs)"; return CSV_ENOMEM; }
+    for (size_t k = 0; k < first_node.size(); k++) {
+        SplitOrderTab e;
+        e.A = 0;
+        uint64_t M = 0, m_max = 0;
+        const uint64_t next_first = k + 1 < first_node.size() ? first_node[k + 1] : ~0ull;
+        for (int c = 0; c < n_contigs; c++) {
+            if (N[(size_t)c] <= first_node[k]) continue;
+            const uint64_t m = std::min(N[(size_t)c], next_first);                 // nodes present at the end of this epoch
+            e.work_off[e.A] = M; e.nbase[e.A] = tab.nbase[c];
+            e.A++; M += m; m_max = std::max(m_max, m);
+        }
+        if (e.A == 0) break;
+        e.work_off[e.A] = M;
+        if (m_max <= 1) continue;                                                   // a single node: nothing to order
+        const uint32_t B = (uint32_t)buckets[k];
+        const int wbits = std::max(1, bits_of(m_max - 1));
+        const int key_bits = 2 * wbits + std::max(1, bits_of((uint64_t)e.A - 1));
+        CSV_HIP(ctx, hipMemsetAsync(minT, 0xff, (size_t)e.A * B * 4, s));
+        launch_so_mint(s, e, M, B, node_hash, pos, minT);
+        launch_so_keys(s, e, M, B, wbits, node_hash, pos, minT, w.k0, w.v0);
+        const int io = launch_radix_sort_u64(s, w.k0, w.v0, w.k1, w.v1, M, key_bits, w.tmp);
+        launch_so_setpos(s, e, M, io ? w.v1 : w.v0, pos);
+    }
+
+    // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
+    const uint64_t cap = n_nodes;
+    csv_split_survivor *d_out = (csv_split_survivor *)arena_alloc(ctx->work, cap * sizeof(csv_split_survivor));
+    unsigned long long *d_count = (unsigned long long *)arena_alloc(ctx->work, 256);
+    if (!d_out || !d_count) { ctx->err = "arena exhausted (split order survivors)"; return CSV_ENOMEM; }
+    CSV_HIP(ctx, hipMemsetAsync(d_count, 0, 8, s));
+    launch_so_survivors(s, tab, n_nodes, node_hash, node_rec, pos, d_supp, n_supp, d_out, cap, d_count);
+    CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_count, 8, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, wait_stream(s));
+    const uint64_t n_surv = *(const unsigned long long *)ctx->pinned;
+    std::vector<csv_split_survivor> surv(n_surv);
+    if (n_surv) {
+        CSV_HIP(ctx, hipMemcpyAsync(surv.data(), d_out, n_surv * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
+        CSV_HIP(ctx, hipStreamSynchronize(s));
+    }
+    std::sort(surv.begin(), surv.end(), [](const csv_split_survivor &a, const csv_split_survivor &b) { return a.contig != b.contig ? a.contig < b.contig : a.pos < b.pos; });
+    for (const csv_split_survivor &v : surv) out_off[v.contig + 1]++;
+    for (int c = 0; c < n_contigs; c++) out_off[c + 1] += out_off[c];
+    if (n_surv > capacity) { ctx->err = "split_order: output capacity too small"; return CSV_ECAPACITY; }
+    for (uint64_t i = 0; i < n_surv; i++) out_rec[i] = surv[i].rec;
     return CSV_OK;
 }
 

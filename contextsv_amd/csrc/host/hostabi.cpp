@@ -325,6 +325,20 @@ int csvhost_split_signatures(csv_ctx *ctx, uint64_t n, const int32_t *tid, const
     })
 }
 
+// std::hash<std::string> of n '\n'-joined names (what the staging code attaches to a shard as its query-name column)
+int csvhost_string_hashes(const char *names, uint64_t n, uint64_t *out)
+{
+    GUARD({
+        const char *p = names;
+        for (uint64_t i = 0; i < n; i++) {
+            const char *e = strchr(p, '\n');
+            const size_t len = e ? (size_t)(e - p) : strlen(p);
+            out[i] = csvhost::std_string_hash(p, len);
+            p = e ? e + 1 : p + len;
+        }
+    })
+}
+
 // Test hook for umap_order.h (CPU): keys = n names ('\n'-joined) inserted in order with operator[], then every key with
 // erase_mask[i] != 0 is erased. order_real = for every surviving node of a real std::unordered_map<std::string,int>, the index of
 // the key's first insertion, in iteration order; order_emu = the same from csvhost::UMapOrder. Returns the count through *n_out
@@ -493,6 +507,7 @@ struct csvhost_genome {
         uint64_t n_reads = 0, n_cigar = 0;
         std::vector<int32_t> pos; std::vector<uint16_t> flag; std::vector<uint8_t> mapq;
         std::vector<uint64_t> qhash, name_id;
+        bool unique_names = false;
         SNPTable snps;
     };
     std::vector<std::unique_ptr<Contig>> contigs;
@@ -527,6 +542,14 @@ int csvhost_genome_add(csvhost_genome *g, csv_ctx *ctx, const char *name, int32_
                 c->qhash[i] = csvhost::std_string_hash(buf, (size_t)len);
                 c->name_id[i] = (name_style ? ((uint64_t)(uint32_t)global_tid << 32) : 0) | qname_id[i];
             }
+            // the query-name column goes to HBM with the shard; and, once, is any name hash shared by two non-supplementary records?
+            // (then the reference's map holds ONE node for them and the contig's order is replayed on the host instead of the device)
+            if (csvgpu_shard_set_qname_hash(ctx, c->shard, c->qhash.data()) != CSV_OK) throw std::runtime_error(std::string("genome_add: ") + csvgpu_last_error(ctx));
+            std::vector<uint64_t> h;
+            h.reserve(n);
+            for (uint64_t i = 0; i < n; i++) if (!(reads->flag[i] & 0x800)) h.push_back(c->qhash[i]);
+            std::sort(h.begin(), h.end());
+            c->unique_names = std::adjacent_find(h.begin(), h.end()) == h.end();
         }
         if (n_snp) {
             c->snps.pos.assign(snp_pos, snp_pos + n_snp); c->snps.baf.assign(snp_baf, snp_baf + n_snp);
@@ -564,7 +587,7 @@ void csvhost_genome_contig_info(const csvhost_genome *g, uint64_t i, uint64_t *n
 }
 
 // One step: SVCaller::runResident over every staged contig. passes: bit 0 split-read pass, bit 1 CIGAR copy-number pass, bit 2 the two
-// final merges. Calls come back grouped by contig in staging order with the contig's GLOBAL tid in out_tid; stats[i] per contig.
+// final merges, bit 3 keep the qname map's order on the host (umap_order.h) instead of csvgpu_split_order. Calls come back grouped by contig in staging order with the contig's GLOBAL tid in out_tid; stats[i] per contig.
 int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *const *lane_ctxs, const csv_hmm *hmm, double eps, double min_pts_pct,
                        int sample_size, uint32_t min_cnv, int passes, int host_threads, csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out,
                        csvhost_stage_times *times, csvhost_chr_stats *stats)
@@ -575,11 +598,12 @@ int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *co
             auto &c = *g->contigs[i];
             rc[i].name = c.name; rc[i].shard = c.shard; rc[i].depth_len = c.depth_len; rc[i].snps = &c.snps;
             rc[i].split.n = c.n_reads; rc[i].split.pos = c.pos.data(); rc[i].split.flag = c.flag.data(); rc[i].split.mapq = c.mapq.data();
-            if (!c.qhash.empty()) { rc[i].split.qhash = c.qhash.data(); rc[i].split.name_id = c.name_id.data(); }
+            if (!c.qhash.empty()) { rc[i].split.qhash = c.qhash.data(); rc[i].split.name_id = c.name_id.data(); rc[i].split.unique_names = c.unique_names; }
         }
         RunParams P; P.dbscan_epsilon = eps; P.dbscan_min_pts_pct = min_pts_pct; P.sample_size = sample_size; P.min_cnv_length = min_cnv;
         P.split_svs = (passes & 1) != 0; P.cigar_cn = (passes & 2) != 0; P.merge_split_svs = P.merge_final_svs = (passes & 4) != 0;
         P.host_threads = host_threads;
+        P.split_order_on_device = (passes & 8) == 0;
         std::vector<csv_ctx *> lanes(lane_ctxs, lane_ctxs + (n_lanes > 0 ? n_lanes : 0));
         SVCaller caller(ctx);
         std::unordered_map<std::string, std::vector<SVCall>> calls;

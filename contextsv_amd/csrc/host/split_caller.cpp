@@ -119,6 +119,7 @@ struct ContigWork {
     std::vector<uint32_t> first_rec, last_rec;     // by node: the record that created the key / the last record of that name (its values win)
     std::vector<SuppRef> supps;                    // this contig's supplementary records, file order
     // survivors (primaries with a supplementary record) in the map's iteration order
+    const std::vector<uint32_t> *dev_order = nullptr;                  // survivors' records in iteration order, when they came from params.device_order
     std::vector<uint32_t> member_rec;                                  // the primary record
     std::vector<std::pair<uint32_t, uint32_t>> member_supp_ref;       // (contig, record) of the supplementary records, all members back to back
     std::vector<size_t> member_supp_off;                               // end of member m's supplementary records in member_supp_ref
@@ -155,21 +156,27 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     }
 
     // ---- phase 1: collect primaries (into the replayed map) and supplementaries (sv_caller.cpp:137-172), per contig ------------
+    // Contigs whose names are known to be unique can get the map's iteration order from params.device_order (the device): for them
+    // only the supplementary records are collected here and the primaries counted.
+    auto on_device = [&](size_t c) { return params.device_order && contigs[c].unique_names; };
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
-        ContigWork &W = work[by_size[k]];
+        const size_t c = by_size[k];
+        ContigWork &W = work[c];
         const SplitContig &C = *W.in;
-        W.order.reserve((size_t)C.n);
+        const bool dev = on_device(c);
+        if (!dev) W.order.reserve((size_t)C.n);
         for (uint64_t i = 0; i < C.n; i++) {
             const uint16_t flag = C.flag[i];
             if ((flag & (FLAG_SECONDARY | FLAG_UNMAP | FLAG_DUP | FLAG_QCFAIL)) || C.mapq[i] < params.min_mapq) continue;
-            if (flag & FLAG_SUPP) { W.supps.push_back(SuppRef{C.qhash[i], C.file_idx ? C.file_idx[i] : (((uint64_t)by_size[k] << 40) | i), (uint32_t)by_size[k], (uint32_t)i}); continue; }
+            if (flag & FLAG_SUPP) { W.supps.push_back(SuppRef{C.qhash[i], C.file_idx ? C.file_idx[i] : (((uint64_t)c << 40) | i), (uint32_t)c, (uint32_t)i}); continue; }
+            if (dev) { W.n_primary++; continue; }
             const int64_t node = W.order.find(C.qhash[i], [&](uint32_t nd) { return same_name(C, W.first_rec[nd], C, i); });
             if (node >= 0) { W.last_rec[(size_t)node] = (uint32_t)i; continue; }        // operator[]: a later record of the name wins (:152)
             W.order.insert_new(C.qhash[i]);
             W.first_rec.push_back((uint32_t)i);
             W.last_rec.push_back((uint32_t)i);
         }
-        W.n_primary = W.first_rec.size();
+        if (!dev) W.n_primary = W.first_rec.size();
     });
 
     // ---- supp_map: every supplementary record of the run by name, file order within a name (:162-165) ---------------------------
@@ -177,21 +184,35 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     for (const ContigWork &W : work) supp_index.insert(supp_index.end(), W.supps.begin(), W.supps.end());
     std::sort(supp_index.begin(), supp_index.end(), [](const SuppRef &a, const SuppRef &b) { return a.hash != b.hash ? a.hash < b.hash : a.ord < b.ord; });
 
+    // ---- the device's share: which primaries have a supplementary record's name hash, in the map's iteration order ----------------
+    std::vector<size_t> dev_contigs;
+    std::vector<std::vector<uint32_t>> dev_recs;
+    for (size_t c = 0; c < contigs.size(); c++) if (on_device(c) && work[c].n_primary) dev_contigs.push_back(c);
+    if (!dev_contigs.empty()) {
+        std::vector<uint64_t> supp_hash;
+        supp_hash.reserve(supp_index.size());
+        for (const SuppRef &r : supp_index) if (supp_hash.empty() || supp_hash.back() != r.hash) supp_hash.push_back(r.hash);
+        params.device_order->survivors(dev_contigs, params.min_mapq, supp_hash, dev_recs);
+        for (size_t k = 0; k < dev_contigs.size(); k++) work[dev_contigs[k]].dev_order = &dev_recs[k];
+    }
+
     // ---- survivors (primaries with a supplementary record, :183-202) in the map's iteration order, with their supplementary records ----
     std::atomic<long> total_removed{0};
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         ContigWork &W = work[by_size[k]];
         const SplitContig &C = *W.in;
-        W.order.for_each([&](uint32_t node) {
-            const uint64_t h = C.qhash[W.first_rec[node]];
+        auto visit = [&](uint32_t first_rec, uint32_t last_rec) {
+            const uint64_t h = C.qhash[first_rec];
             auto lo = std::lower_bound(supp_index.begin(), supp_index.end(), h, [](const SuppRef &a, uint64_t x) { return a.hash < x; });
             const size_t before = W.member_supp_ref.size();
             for (; lo != supp_index.end() && lo->hash == h; ++lo)
-                if (same_name(C, W.first_rec[node], *work[lo->contig].in, lo->rec)) W.member_supp_ref.push_back(std::make_pair(lo->contig, lo->rec));   // (equal hash, other name: skipped)
+                if (same_name(C, first_rec, *work[lo->contig].in, lo->rec)) W.member_supp_ref.push_back(std::make_pair(lo->contig, lo->rec));   // (equal hash, other name: skipped)
             if (W.member_supp_ref.size() == before) return;                             // erased: no supplementary record
-            W.member_rec.push_back(W.last_rec[node]);
+            W.member_rec.push_back(last_rec);
             W.member_supp_off.push_back(W.member_supp_ref.size());
-        });
+        };
+        if (W.dev_order) for (uint32_t r : *W.dev_order) visit(r, r);
+        else W.order.for_each([&](uint32_t node) { visit(W.first_rec[node], W.last_rec[node]); });
         total_removed += (long)(W.n_primary - W.member_rec.size());
         W.order = csvhost::UMapOrder(); W.first_rec = {}; W.last_rec = {};             // the map's storage is not needed any more
     });

@@ -27,12 +27,22 @@ struct SplitRecord {
     int32_t  q_end;      // query_end            }  or csvgpu_aln_intervals)
 };
 
+// The surviving primaries of several contigs, each in the iteration order of the reference's per-chromosome qname map, computed
+// somewhere else than on this host thread (the device: csvgpu_split_order behind ShardOrderSource in sv_caller.cpp).
+struct SplitOrderSource {
+    virtual ~SplitOrderSource() = default;
+    // which[k] indexes the `contigs` vector of findSplitSVSignatures; recs[k] = record indices of contig which[k]'s primaries whose name
+    // hash is in supp_hash (sorted, distinct), in iteration order. Only asked for contigs with SplitContig::unique_names.
+    virtual void survivors(const std::vector<size_t> &which, int min_mapq, const std::vector<uint64_t> &supp_hash, std::vector<std::vector<uint32_t>> &recs) const = 0;
+};
+
 struct SplitParams {
     int min_mapq = 20;        // sv_caller.h:72
     double eps = 100;         // DBSCAN1D(100, 5) at sv_caller.cpp:270
     int min_pts = 5;
     int min_length = 2000;    // :243
     int max_length = 1000000; // :244
+    const SplitOrderSource *device_order = nullptr;   // where contigs with unique_names get their iteration order from (nullptr: replayed on the host)
     int threads = 0;          // host threads over contigs (0: one per contig, at most the hardware's); the result does not depend on it
 };
 
@@ -60,6 +70,7 @@ struct SplitContig {
     const uint64_t *name_id = nullptr;
     const char *name_bytes = nullptr;
     const uint64_t *name_off = nullptr;      // [n + 1]
+    bool unique_names = false;               // established when the contig was staged: no two non-supplementary records share a name hash
     const uint64_t *file_idx = nullptr;      // optional: position of each record in the file (default: contigs in the order given, records in array order)
 };
 

@@ -326,6 +326,32 @@ struct ShardIntervals : IntervalSource {
     csv_shard *shard;
 };
 
+// the iteration order of the reference's per-chromosome qname map from the device (csvgpu_split_order): shard_of[c] is the resident
+// shard of split-pass contig c (its query-name hashes were attached when it was staged)
+struct ShardOrderSource : SplitOrderSource {
+    ShardOrderSource(csv_ctx *ctx, std::vector<csv_shard *> shard_of) : ctx(ctx), shard_of(std::move(shard_of)) {}
+    void survivors(const std::vector<size_t> &which, int min_mapq, const std::vector<uint64_t> &supp_hash, std::vector<std::vector<uint32_t>> &recs) const override
+    {
+        recs.assign(which.size(), {});
+        for (size_t b0 = 0; b0 < which.size(); b0 += 32) {                       // the entry point takes up to 32 contigs per call
+            const size_t nb = std::min<size_t>(32, which.size() - b0);
+            std::vector<csv_shard *> sh(nb);
+            for (size_t k = 0; k < nb; k++) sh[k] = shard_of[which[b0 + k]];
+            std::vector<uint64_t> off(nb + 1, 0);
+            std::vector<uint32_t> out(std::max<size_t>(supp_hash.size() * 2, 1024));
+            int rc = csvgpu_split_order(ctx, (int)nb, sh.data(), (uint8_t)min_mapq, supp_hash.data(), supp_hash.size(), out.data(), out.size(), off.data());
+            if (rc == CSV_ECAPACITY) {
+                out.resize(off[nb]);
+                rc = csvgpu_split_order(ctx, (int)nb, sh.data(), (uint8_t)min_mapq, supp_hash.data(), supp_hash.size(), out.data(), out.size(), off.data());
+            }
+            check(ctx, rc, "split-read order");
+            for (size_t k = 0; k < nb; k++) recs[b0 + k].assign(out.begin() + (std::ptrdiff_t)off[k], out.begin() + (std::ptrdiff_t)off[k + 1]);
+        }
+    }
+    csv_ctx *ctx;
+    std::vector<csv_shard *> shard_of;
+};
+
 struct EmptySnps : SNPSource {
     void query(uint32_t, uint32_t, std::vector<uint32_t> &, std::unordered_map<uint32_t, double> &, std::unordered_map<uint32_t, double> &) const override {}
 };
@@ -509,6 +535,10 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         t0 = now_ms();
         std::unordered_map<std::string, std::vector<SVCall>> split_calls;
         SplitParams sp; sp.min_mapq = min_mapq; sp.threads = P.host_threads;
+        std::vector<csv_shard *> shard_of;
+        for (const SplitContig &b : blocks) shard_of.push_back(contigs[(size_t)b.tid].shard);
+        const ShardOrderSource dev_order(ctx, shard_of);
+        if (P.split_order_on_device) sp.device_order = &dev_order;                 // only contigs staged with unique_names take it
         findSplitSVSignatures(blocks, names, sp, split_calls);
         T.ms_split = now_ms() - t0;
         t0 = now_ms();

@@ -1,0 +1,169 @@
+// splitorder.hip — §8f-4, the part of the split-read pass that scales with the read count: the ITERATION ORDER of the reference's
+// `unordered_map<std::string, PrimaryAlignment>` per chromosome (src/sv_caller.cpp:137-172 fills it with every primary alignment,
+// :183-202 erases those without a supplementary record, :216 / :224 iterate what is left: tree insertion order and group seeds).
+//
+// libstdc++'s _Hashtable keeps ONE singly linked node list; a node is always put at the front of its bucket, a bucket that becomes
+// non-empty goes to the front of the list, and a rehash re-inserts the nodes in list order by the same two rules (host/umap_order.h
+// replays this node by node). Between two rehashes ("epoch", bucket count B) that is a closed form: give every node present at the
+// end of the epoch its processing time t — its position in the list when the epoch began, or its insertion index if it came later —
+// then the list at the end of the epoch is the nodes sorted by (min t of the node's bucket, descending; t, descending).
+// So the order of N keys is a chain of ~log2(N) stable sorts of geometrically growing size (~2N keys sorted in all), each of them:
+//   so_mint   minT[bucket] = min t            (atomicMin; bucket = hash % B, B from the library's own _Prime_rehash_policy)
+//   so_keys   key = contig | ~minT | ~t       (all contigs of the genome share every launch)
+//   radix sort (sort.hip), so_setpos           position of every node in the new list
+// and the survivors (nodes whose name hash is among the supplementary records' hashes) leave with their final position.
+// Checked against umap_order.h (which is checked against the real container) in tests/test_gpu_split_order.py.
+#include "../common.hpp"
+#include "../devutil.hpp"
+
+namespace csv {
+
+constexpr int SO_THREADS = 256;
+constexpr int SO_BLOCK = 1024;          // records per compaction block
+
+// which contig owns block / work item x, given the exclusive prefix table off[0..A] (A <= SO_MAX_CONTIGS)
+__device__ __forceinline__ uint32_t so_owner(const SplitOrderTab &t, uint64_t x, const uint64_t *off)
+{
+    uint32_t a = 0;
+    for (uint32_t k = 1; k < t.A; k++) a += (x >= off[k]);       // A is small (<= 64): a linear scan of scalar loads
+    return a;
+}
+
+__device__ __forceinline__ bool so_pass(uint16_t flag, uint8_t mapq, uint32_t min_mapq)
+{
+    // sv_caller.cpp:145-150 (filter) and :151 (primary = not supplementary)
+    return !(flag & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && mapq >= min_mapq;
+}
+
+// ---- nodes = the filter-passing primary records in file order (the insertion order of the map) ------------------------------------
+__global__ __launch_bounds__(SO_THREADS) void so_count_kernel(SplitOrderTab tab, uint32_t min_mapq, uint32_t *__restrict__ blk_cnt)
+{
+    const uint32_t a = so_owner(tab, blockIdx.x, tab.blk_off);
+    const uint64_t r0 = (uint64_t)(blockIdx.x - tab.blk_off[a]) * SO_BLOCK;
+    const uint64_t n = tab.n_reads[a];
+    uint32_t c = 0;
+    for (int k = threadIdx.x; k < SO_BLOCK; k += SO_THREADS) {
+        const uint64_t r = r0 + k;
+        if (r < n) c += so_pass(tab.flag[a][r], tab.mapq[a][r], min_mapq);
+    }
+    c = wave_sum(c);
+    __shared__ uint32_t ws[SO_THREADS / WAVE];
+    if (lane_id() == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < SO_THREADS / WAVE; w++) t += ws[w]; blk_cnt[blockIdx.x] = t; }
+}
+
+// blk_off = exclusive sum of blk_cnt over ALL blocks: a contig's first block holds its first node's global index
+__global__ __launch_bounds__(SO_THREADS) void so_scatter_kernel(SplitOrderTab tab, uint32_t min_mapq, const uint32_t *__restrict__ blk_off,
+                                                                uint64_t *__restrict__ node_hash, uint32_t *__restrict__ node_rec, uint32_t *__restrict__ pos)
+{
+    const uint32_t a = so_owner(tab, blockIdx.x, tab.blk_off);
+    const uint64_t r0 = (uint64_t)(blockIdx.x - tab.blk_off[a]) * SO_BLOCK;
+    const uint64_t n = tab.n_reads[a];
+    const uint32_t contig_base = blk_off[tab.blk_off[a]];
+    __shared__ uint32_t ws[SO_THREADS / WAVE];
+    uint32_t base = blk_off[blockIdx.x];
+    for (int k0 = 0; k0 < SO_BLOCK; k0 += SO_THREADS) {
+        const uint64_t r = r0 + k0 + threadIdx.x;
+        const bool p = r < n && so_pass(tab.flag[a][r], tab.mapq[a][r], min_mapq);
+        const uint64_t bal = __ballot(p);
+        const uint32_t before = (uint32_t)__popcll(bal & lanemask_lt());
+        if (lane_id() == 0) ws[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (int w = 0; w < SO_THREADS / WAVE; w++) { if (w < (int)(threadIdx.x >> 6)) wbase += ws[w]; tot += ws[w]; }
+        if (p) {
+            const uint32_t g = base + wbase + before;
+            node_hash[g] = tab.qhash[a][r];
+            node_rec[g] = (uint32_t)r;
+            pos[g] = g - contig_base;                      // not yet in any list: its processing time is its insertion index
+        }
+        base += tot;
+        __syncthreads();
+    }
+}
+
+// ---- one epoch ------------------------------------------------------------------------------------------------------------------------
+// work item j of active contig a (tab.work_off) = node nbase[a] + (j - work_off[a]), i.e. the nodes inserted so far
+__global__ __launch_bounds__(SO_THREADS) void so_mint_kernel(SplitOrderTab tab, uint64_t M, uint32_t B, const uint64_t *__restrict__ node_hash,
+                                                             const uint32_t *__restrict__ pos, uint32_t *__restrict__ minT)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
+    if (j >= M) return;
+    const uint32_t a = so_owner(tab, j, tab.work_off);
+    const uint32_t g = tab.nbase[a] + (uint32_t)(j - tab.work_off[a]);
+    const uint32_t b = (uint32_t)(node_hash[g] % (uint64_t)B);
+    atomicMin(&minT[(uint64_t)a * B + b], pos[g]);
+}
+
+__global__ __launch_bounds__(SO_THREADS) void so_keys_kernel(SplitOrderTab tab, uint64_t M, uint32_t B, int w, const uint64_t *__restrict__ node_hash,
+                                                             const uint32_t *__restrict__ pos, const uint32_t *__restrict__ minT,
+                                                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
+    if (j >= M) return;
+    const uint32_t a = so_owner(tab, j, tab.work_off);
+    const uint32_t g = tab.nbase[a] + (uint32_t)(j - tab.work_off[a]);
+    const uint32_t b = (uint32_t)(node_hash[g] % (uint64_t)B);
+    const uint64_t mask = (1ull << w) - 1ull;
+    // ascending sort: contig, then LARGER bucket time first, then LARGER own time first
+    keys[j] = ((uint64_t)a << (2 * w)) | ((mask - (uint64_t)minT[(uint64_t)a * B + b]) << w) | (mask - (uint64_t)pos[g]);
+    vals[j] = g;
+}
+
+__global__ __launch_bounds__(SO_THREADS) void so_setpos_kernel(SplitOrderTab tab, uint64_t M, const uint32_t *__restrict__ vals, uint32_t *__restrict__ pos)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
+    if (j >= M) return;
+    const uint32_t a = so_owner(tab, j, tab.work_off);
+    pos[vals[j]] = (uint32_t)(j - tab.work_off[a]);
+}
+
+// ---- the nodes that survive the erase: their name hash is among the supplementary records' (sorted, distinct) hashes ----------------
+__global__ __launch_bounds__(SO_THREADS) void so_survivors_kernel(SplitOrderTab tab, uint64_t n_nodes, const uint64_t *__restrict__ node_hash,
+                                                                  const uint32_t *__restrict__ node_rec, const uint32_t *__restrict__ pos,
+                                                                  const uint64_t *__restrict__ supp_hash, uint64_t n_supp, csv_split_survivor *__restrict__ out,
+                                                                  uint64_t cap, unsigned long long *__restrict__ count)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
+    if (g >= n_nodes) return;
+    const uint64_t h = node_hash[g];
+    uint64_t lo = 0, hi = n_supp;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (supp_hash[mid] < h) lo = mid + 1; else hi = mid; }
+    if (lo >= n_supp || supp_hash[lo] != h) return;
+    uint32_t a = 0;
+    for (uint32_t k = 1; k < tab.A; k++) a += (g >= tab.nbase[k]);
+    const unsigned long long slot = atomicAdd(count, 1ull);
+    if (slot < cap) out[slot] = csv_split_survivor{a, pos[g], node_rec[g]};
+}
+
+void launch_so_count(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, uint32_t *blk_cnt)
+{
+    if (n_blocks) hipLaunchKernelGGL(so_count_kernel, dim3(n_blocks), dim3(SO_THREADS), 0, s, tab, min_mapq, blk_cnt);
+}
+void launch_so_scatter(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, const uint32_t *blk_off, uint64_t *node_hash,
+                       uint32_t *node_rec, uint32_t *pos)
+{
+    if (n_blocks) hipLaunchKernelGGL(so_scatter_kernel, dim3(n_blocks), dim3(SO_THREADS), 0, s, tab, min_mapq, blk_off, node_hash, node_rec, pos);
+}
+static inline unsigned so_grid(uint64_t n) { return (unsigned)((n + SO_THREADS - 1) / SO_THREADS); }
+void launch_so_mint(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, const uint64_t *node_hash, const uint32_t *pos, uint32_t *minT)
+{
+    if (M) hipLaunchKernelGGL(so_mint_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, B, node_hash, pos, minT);
+}
+void launch_so_keys(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, int w, const uint64_t *node_hash, const uint32_t *pos,
+                    const uint32_t *minT, uint64_t *keys, uint32_t *vals)
+{
+    if (M) hipLaunchKernelGGL(so_keys_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, B, w, node_hash, pos, minT, keys, vals);
+}
+void launch_so_setpos(hipStream_t s, const SplitOrderTab &tab, uint64_t M, const uint32_t *vals, uint32_t *pos)
+{
+    if (M) hipLaunchKernelGGL(so_setpos_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, vals, pos);
+}
+void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nodes, const uint64_t *node_hash, const uint32_t *node_rec, const uint32_t *pos,
+                         const uint64_t *supp_hash, uint64_t n_supp, csv_split_survivor *out, uint64_t cap, unsigned long long *count)
+{
+    if (n_nodes) hipLaunchKernelGGL(so_survivors_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, tab, n_nodes, node_hash, node_rec, pos, supp_hash, n_supp, out, cap, count);
+}
+
+}  // namespace csv

@@ -136,6 +136,7 @@ def load() -> C.CDLL:
                                        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(stage_times), _P]
     lib.csvhost_sig_alts.argtypes = [_P, C.c_uint64, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_process_resident_chromosome_alts.argtypes = [_P, _P, _P, _P, C.c_double, C.c_double, _P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.csvhost_string_hashes.argtypes = [C.c_char_p, C.c_uint64, _P]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -271,7 +272,7 @@ class Genome:
         return {"n_reads": nr.value, "n_cigar": nc.value, "depth_len": dl.value, "global_tid": gt.value, "shard": sh.value}
 
     def run(self, ctx: Context, hmm, lanes=None, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True, cigar_cn=True, merges=True,
-            host_threads=0, capacity: int = 1 << 20):
+            host_threads=0, capacity: int = 1 << 20, host_split_order: bool = False):
         """-> (calls[CALL_DTYPE], global tid per call, stage_times, per-contig chr_stats list)"""
         n = len(self)
         out = np.zeros(capacity, CALL_DTYPE)
@@ -282,7 +283,7 @@ class Genome:
         lanes = lanes or []
         lp = (C.c_void_p * max(len(lanes), 1))(*[c.h for c in lanes])
         _check(load().csvhost_genome_run(self.h, ctx.h, len(lanes), lp, C.byref(hmm), eps, min_pts_pct, sample_size, min_cnv,
-                                         int(split_svs) | (int(cigar_cn) << 1) | (int(merges) << 2), host_threads, out.ctypes.data, tid.ctypes.data, capacity,
+                                         int(split_svs) | (int(cigar_cn) << 1) | (int(merges) << 2) | (int(host_split_order) << 3), host_threads, out.ctypes.data, tid.ctypes.data, capacity,
                                          C.byref(k), C.byref(st), cs))
         if k.value > capacity:
             raise RuntimeError("Genome.run: capacity too small")
@@ -292,6 +293,13 @@ class Genome:
         if self.h:
             load().csvhost_genome_free(self.h)
             self.h = None
+
+
+def string_hashes(names) -> np.ndarray:
+    """libstdc++ std::hash<std::string> of every name (uint64)."""
+    out = np.zeros(max(len(names), 1), np.uint64)
+    _check(load().csvhost_string_hashes("\n".join(names).encode(), len(names), out.ctypes.data))
+    return out[: len(names)]
 
 
 def umap_order_check(keys, erase_mask=None):

@@ -97,7 +97,8 @@ typedef enum csv_kernel_id {
     CSV_K_WINDOW     = 5,   /* window log2 coverage */
     CSV_K_VITERBI    = 6,   /* emissions + Viterbi DP + backtrack */
     CSV_K_MISC       = 7,   /* memsets, small scans, partition */
-    CSV_K_COUNT      = 8
+    CSV_K_SPLIT_ORDER = 8,  /* hash-map node order of the split-read pass (compaction + per-epoch sorts + survivors) */
+    CSV_K_COUNT      = 9
 } csv_kernel_id;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -289,6 +290,22 @@ int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *shard, int32_t *ref_e
 /* The same for selected records only: ref_end[i] / q_start[i] / q_end[i] of record rec[i] (the split-read pass needs the intervals of
  * the primaries that have a supplementary record and of those records — a few per cent of a contig; sv_caller.cpp:152, :162). */
 int csvgpu_aln_intervals_gather_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *rec, uint64_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end);
+
+/* The query-name column of a resident shard: qname_hash[i] = std::hash<std::string> (libstdc++) of record i's query name — the value that
+ * decides where the reference's unordered_map<std::string, PrimaryAlignment> puts the read (sv_caller.cpp:152). Copied to HBM, owned by the shard. */
+int csvgpu_shard_set_qname_hash(csv_ctx *ctx, csv_shard *shard, const uint64_t *qname_hash);
+
+/* §8f-4: which primary alignments survive, and in which order the reference iterates them — for up to 32 contigs in one call.
+ * For every contig the reference fills an unordered_map keyed by query name with every record that passes the filter of sv_caller.cpp:145
+ * (not SECONDARY/UNMAP/DUP/QCFAIL, mapq >= min_mapq) and is not supplementary, in file order (:137-172); erases the names without a
+ * supplementary record (:183-202); then iterates the map (:216, :224). Given the (sorted, distinct) name hashes of the run's supplementary
+ * records, this returns per contig the record indices of the surviving primaries in that iteration order: out_rec[out_off[c] .. out_off[c+1]).
+ * A record "survives" here when its name HASH is in supp_hash — the caller confirms the names (a 64-bit collision is the only difference).
+ * Precondition (caller's to check when it stages the shard): within a contig no two non-supplementary records share a name hash
+ * (no repeated query names, no 64-bit collisions) — otherwise the map would hold one node for two records and the host form
+ * (host/umap_order.h) has to be used for that contig. CSV_ECAPACITY: out_rec too small, out_off[n_contigs] holds the required count. */
+int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq, const uint64_t *supp_hash, uint64_t n_supp,
+                       uint32_t *out_rec, uint64_t capacity, uint64_t *out_off);
 
 /* csvgpu_window_log2 on the depth map that the last csvgpu_chr_pipeline_dev() left resident in `shard`
  * (region tables and outputs are host memory; the depth map never leaves HBM). */

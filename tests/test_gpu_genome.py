@@ -37,8 +37,9 @@ def test_resident_run_equals_uploading_run(ctx):
     assert np.array_equal(tid, ref_tid)
     _same(got, ref_calls)
     assert st.n_reads == sum(c["reads"].n_reads for c in contigs) and st.n_final_calls == len(got) and st.n_cigar_cn_regions > 0 and st.n_split_calls > 0
-    # again (nothing was consumed), with one host thread, and through three lanes behind a gate
-    got2, tid2, _, _ = g.run(ctx, hmm, host_threads=1)
+    # again (nothing was consumed), with one host thread and the qname map's order replayed on the host instead of the device,
+    # and through three lanes behind a gate
+    got2, tid2, _, _ = g.run(ctx, hmm, host_threads=1, host_split_order=True)
     assert np.array_equal(tid2, ref_tid)
     _same(got2, ref_calls)
     lanes = [cs.Context(0) for _ in range(3)]

@@ -1,0 +1,71 @@
+"""§8f-4: csvgpu_split_order — the iteration order of the reference's per-chromosome `unordered_map<std::string, PrimaryAlignment>`
+(src/sv_caller.cpp:137-172 fill, :183-202 erase, :216 / :224 iterate) computed on the device as a chain of per-epoch sorts —
+against a REAL std::unordered_map<std::string,int> filled and erased the same way (host.umap_order_check's first output).
+Contig sizes sit on both sides of every rehash threshold up to 4e5 nodes; filtered records, supplementary records, names without a
+supplementary record and supplementary hashes that belong to no primary are mixed in."""
+import numpy as np
+import pytest
+
+from contextsv_amd import Reads, host
+
+pytestmark = pytest.mark.gpu
+
+
+def _contig(rng, tid, n):
+    flag = rng.choice([0, 16, 0x800, 0x810, 0x100, 0x400, 0x200, 0x4], n, p=[.42, .42, .03, .03, .03, .03, .02, .02]).astype(np.uint16)
+    mapq = rng.choice([60, 60, 60, 20, 19, 0], n).astype(np.uint8)
+    names = ["r%d_%d" % (tid, i) for i in range(n)]
+    pos = np.sort(rng.integers(0, 10_000_000, n)).astype(np.int32)
+    reads = Reads.from_cigar_lists(pos, flag, mapq, [[(0, 100)]] * n) if n < 3000 else \
+        Reads(pos, flag, mapq, np.arange(n + 1, dtype=np.uint64), np.full(n, (100 << 4), np.uint32))
+    return reads, names
+
+
+@pytest.mark.parametrize("sizes", [[0, 1, 2, 12, 13, 14, 28, 29, 30, 58, 59, 60, 126, 127, 128, 257, 541, 542, 1109, 2357, 2358, 5087, 5088],
+                                   [10273, 10274, 20753, 42043, 42044, 85229, 85230, 3],
+                                   [172933, 172934, 351061, 351062, 400_000]])
+def test_split_order_against_a_real_unordered_map(ctx, sizes):
+    rng = np.random.default_rng(len(sizes))
+    contigs = [_contig(rng, t, n) for t, n in enumerate(sizes)]
+    shards = []
+    supp_names = []
+    per = []
+    try:
+        for t, (reads, names) in enumerate(contigs):
+            h = host.string_hashes(names)
+            sh = ctx.upload(reads, 10_000_001)
+            sh.set_qname_hash(h)
+            shards.append(sh)
+            ok = ((reads.flag & (0x100 | 0x4 | 0x400 | 0x200)) == 0) & (reads.mapq >= 20)
+            prim = np.flatnonzero(ok & ((reads.flag & 0x800) == 0))
+            # supplementary names: a tenth of the primaries' names (+ a few names that belong to no primary)
+            has_supp = rng.random(len(prim)) < 0.1
+            per.append((names, prim, has_supp))
+            supp_names += [names[i] for i in prim[has_supp]] + ["ghost%d_%d" % (t, k) for k in range(3)]
+        supp_hash = np.unique(host.string_hashes(supp_names))
+        got = ctx.split_order(shards, 20, supp_hash)
+        for t, (names, prim, has_supp) in enumerate(per):
+            keys = [names[i] for i in prim]
+            order_real, order_emu, buckets = host.umap_order_check(keys, (~has_supp).astype(np.uint8))
+            assert np.array_equal(order_real, order_emu)
+            exp = prim[order_real].astype(np.uint32)
+            assert np.array_equal(got[t], exp), (t, len(names), len(exp))
+    finally:
+        for sh in shards:
+            sh.free()
+
+
+def test_split_order_argument_checks(ctx):
+    reads = Reads.from_cigar_lists([1, 2], [0, 0], [60, 60], [[(0, 10)], [(0, 10)]])
+    sh = ctx.upload(reads, 100)
+    try:
+        with pytest.raises(Exception):                      # no query-name hashes attached
+            ctx.split_order([sh], 20, np.array([1, 2], np.uint64))
+        sh.set_qname_hash(np.array([5, 9], np.uint64))
+        with pytest.raises(Exception):                      # supplementary hashes not sorted
+            ctx.split_order([sh], 20, np.array([9, 5], np.uint64))
+        assert [x.tolist() for x in ctx.split_order([sh], 20, np.array([], np.uint64))] == [[]]
+        got = ctx.split_order([sh], 20, np.array([5, 9], np.uint64))
+        assert sorted(got[0].tolist()) == [0, 1]
+    finally:
+        sh.free()
