@@ -83,6 +83,7 @@ ABI = {
     "csvgpu_host_free": (None, [_P, _P]),
     "csvgpu_aln_intervals_resident": (C.c_int, [_P, _P, _P, _P, _P]),
     "csvgpu_aln_intervals_gather_resident": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P]),
+    "csvgpu_aln_intervals_gather_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "csvgpu_shard_set_qname_hash": (C.c_int, [_P, _P, _P]),
     "csvgpu_split_order": (C.c_int, [_P, C.c_int, _P, C.c_uint8, _P, C.c_uint64, _P, C.c_uint64, _P]),
     "csvgpu_window_log2_resident": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_double, _P, _P, _P]),

@@ -879,12 +879,19 @@ int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *sh, int32_t *ref_end,
     return CSV_OK;
 }
 
-int csvgpu_aln_intervals_gather_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *rec, uint64_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end)
+int csvgpu_aln_intervals_gather_batch(csv_ctx *ctx, int n_shards, csv_shard *const *shards, const uint32_t *rec, const uint64_t *rec_off,
+                                      int32_t *ref_end, int32_t *q_start, int32_t *q_end)
 {
-    if (!ctx || !sh) return CSV_EINVAL;
+    if (!ctx || n_shards < 0) return CSV_EINVAL;
+    if (n_shards == 0) return CSV_OK;
+    if (!shards || !rec_off) { ctx->err = "aln_intervals_gather: null array"; return CSV_EINVAL; }
+    const uint64_t n = rec_off[n_shards];
     if (n == 0) return CSV_OK;
     if (!rec || !ref_end || !q_start || !q_end) { ctx->err = "aln_intervals_gather: null array"; return CSV_EINVAL; }
-    for (uint64_t i = 0; i < n; i++) if (rec[i] >= sh->d.n_reads) { ctx->err = "aln_intervals_gather: record index beyond the shard"; return CSV_EINVAL; }
+    for (int c = 0; c < n_shards; c++) {
+        if (!shards[c] || rec_off[c + 1] < rec_off[c]) { ctx->err = "aln_intervals_gather: bad shard table"; return CSV_EINVAL; }
+        for (uint64_t i = rec_off[c]; i < rec_off[c + 1]; i++) if (rec[i] >= shards[c]->d.n_reads) { ctx->err = "aln_intervals_gather: record index beyond the shard"; return CSV_EINVAL; }
+    }
     (void)hipSetDevice(ctx->device);
     int rc = arena_reserve(ctx, ctx->arena, 4 * align_up(n * 4, 256) + 4096);
     if (rc) return rc;
@@ -894,14 +901,24 @@ int csvgpu_aln_intervals_gather_resident(csv_ctx *ctx, csv_shard *sh, const uint
     if (!didx || !dout[0] || !dout[1] || !dout[2]) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     hipStream_t s = ctx->stream;
     CSV_HIP(ctx, hipMemcpyAsync(didx, rec, n * 4, hipMemcpyHostToDevice, s));
-    const int32_t *src[3] = {sh->ref_end, sh->q_start, sh->q_end};
-    int32_t *dst[3] = {ref_end, q_start, q_end};
-    for (int k = 0; k < 3; k++) {
-        launch_gather_u32(s, (const uint32_t *)src[k], didx, n, dout[k]);
-        CSV_HIP(ctx, hipMemcpyAsync(dst[k], dout[k], n * 4, hipMemcpyDeviceToHost, s));
+    for (int c = 0; c < n_shards; c++) {
+        const uint64_t o = rec_off[c], m = rec_off[c + 1] - o;
+        if (!m) continue;
+        const csv_shard *sh = shards[c];
+        launch_gather_u32(s, (const uint32_t *)sh->ref_end, didx + o, m, dout[0] + o);
+        launch_gather_u32(s, (const uint32_t *)sh->q_start, didx + o, m, dout[1] + o);
+        launch_gather_u32(s, (const uint32_t *)sh->q_end, didx + o, m, dout[2] + o);
     }
+    int32_t *dst[3] = {ref_end, q_start, q_end};
+    for (int k = 0; k < 3; k++) CSV_HIP(ctx, hipMemcpyAsync(dst[k], dout[k], n * 4, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, hipStreamSynchronize(s));
     return CSV_OK;
+}
+
+int csvgpu_aln_intervals_gather_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *rec, uint64_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end)
+{
+    const uint64_t off[2] = {0, n};
+    return csvgpu_aln_intervals_gather_batch(ctx, 1, &sh, rec, off, ref_end, q_start, q_end);
 }
 
 int csvgpu_shard_set_qname_hash(csv_ctx *ctx, csv_shard *sh, const uint64_t *qname_hash)

@@ -44,11 +44,25 @@ Genotype CNVCaller::getGenotypeFromCNState(int cn_state)
 
 // ---- querySNPRegion, batched ---------------------------------------------------------------------------------------------------
 // One RegionBatch = the regions of one contig: (A) SNP look-ups per region, (B) ONE window launch on the contig's resident depth map,
-// (C) the observation vectors per region. A and C are independent per region and run on the host pool.
+// (C) the observation vectors per region. A and C are independent per region and run on the host pool in chunks of kChunk regions,
+// every chunk appending to its own flat arrays (a genome has ~1e4 regions of ~25 observations: per-region containers were most
+// of the pass's time).
+namespace { constexpr size_t kChunk = 64; }
+
+struct CNVCaller::SnpChunk {                   // SNPs of up to kChunk regions back to back
+    std::vector<uint32_t> pos;
+    std::vector<double> baf, pfb;              // the values the reference's two hash maps hold for pos[i] (pfb: 0.0 when it has none)
+    std::vector<uint32_t> off{0};
+};
+struct CNVCaller::ObsChunk {                   // observation vectors of up to kChunk regions back to back
+    std::vector<uint32_t> pos;
+    std::vector<double> baf, pfb, l2;
+    std::vector<uint8_t> is_snp;
+    std::vector<uint64_t> off{0};
+};
 struct CNVCaller::RegionBatch {
-    struct RegionSnps { std::vector<uint32_t> pos; std::unordered_map<uint32_t, double> baf, pfb; };
     std::vector<std::pair<uint32_t, uint32_t>> regions;
-    std::vector<RegionSnps> rs;
+    std::vector<SnpChunk> snp;                 // region i: chunk i / kChunk, entry i % kChunk
     std::vector<uint32_t> r_start, r_end;
     std::vector<int32_t> r_ss;
     std::vector<uint64_t> win_off{0};
@@ -57,19 +71,56 @@ struct CNVCaller::RegionBatch {
     std::vector<uint32_t> ws, we;
 };
 
+void SNPSource::queryFlat(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos, std::vector<double> &baf_at, std::vector<double> &pfb_at) const
+{
+    std::vector<uint32_t> pos;
+    std::unordered_map<uint32_t, double> baf, pfb;
+    query(start_pos, end_pos, pos, baf, pfb);
+    for (uint32_t p : pos) {
+        snp_pos.push_back(p);
+        baf_at.push_back(baf[p]);
+        const auto f = pfb.find(p);
+        pfb_at.push_back(f != pfb.end() ? f->second : 0.0);      // operator[] default-constructs 0.0 (cnv_caller.cpp:138)
+    }
+}
+
+// sorted arrays: duplicates of a position are neighbours, and the maps keep the LAST duplicate's value
+void SNPTable::queryFlat(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos, std::vector<double> &baf_at, std::vector<double> &pfb_at) const
+{
+    const size_t a = std::lower_bound(pos.begin(), pos.end(), start_pos) - pos.begin();
+    size_t b = a;
+    while (b < pos.size() && pos[b] <= end_pos) b++;
+    for (size_t i = a; i < b;) {
+        size_t j = i;
+        while (j + 1 < b && pos[j + 1] == pos[i]) j++;
+        double f = 0.0;
+        if (!has_pfb.empty()) for (size_t k = i; k <= j; k++) if (has_pfb[k]) f = pfb[k];
+        for (size_t k = i; k <= j; k++) { snp_pos.push_back(pos[i]); baf_at.push_back(baf[j]); pfb_at.push_back(f); }
+        i = j + 1;
+    }
+}
+
 void CNVCaller::prepareWindows(RegionBatch &B, const SNPSource &snps) const
 {
     const size_t n = B.regions.size();
-    B.rs.assign(n, RegionBatch::RegionSnps());
+    B.snp.assign((n + kChunk - 1) / kChunk, SnpChunk());
     B.slot.assign(n, SIZE_MAX);
-    csvhost::parallel_for(n, host_threads, [&](size_t i) { snps.query(B.regions[i].first, B.regions[i].second, B.rs[i].pos, B.rs[i].baf, B.rs[i].pfb); });
+    csvhost::parallel_for(B.snp.size(), host_threads, [&](size_t c) {
+        SnpChunk &ch = B.snp[c];
+        for (size_t i = c * kChunk; i < std::min(n, (c + 1) * kChunk); i++) {
+            snps.queryFlat(B.regions[i].first, B.regions[i].second, ch.pos, ch.baf, ch.pfb);
+            ch.off.push_back((uint32_t)ch.pos.size());
+        }
+    });
     for (size_t i = 0; i < n; i++) {
         const uint32_t start_pos = B.regions[i].first, end_pos = B.regions[i].second;
         if (start_pos > end_pos) {                          // the reference logs and leaves snp_data empty (cnv_caller.cpp:69-73)
             printError("ERROR: Invalid SNP region for copy number prediction: " + std::to_string((int)start_pos) + "-" + std::to_string((int)end_pos));
             continue;
         }
-        const int ss = std::max((int)B.rs[i].pos.size(), sample_size);   // :65
+        const SnpChunk &ch = B.snp[i / kChunk];
+        const int n_snps = (int)(ch.off[i % kChunk + 1] - ch.off[i % kChunk]);
+        const int ss = std::max(n_snps, sample_size);       // :65
         B.slot[i] = B.r_start.size();
         B.r_start.push_back(start_pos); B.r_end.push_back(end_pos); B.r_ss.push_back(ss);
         B.win_off.push_back(B.win_off.back() + (uint64_t)ss);
@@ -88,44 +139,46 @@ void CNVCaller::launchWindows(RegionBatch &B, csv_shard *shard, double mean_chr_
 // The reference keys the windows by the string "ws-we" in an unordered_map<std::string,double>: equal keys collapse (the later window's
 // value wins, the node stays where the first put it) and the iteration order of that libstdc++ container is the observation order
 // (:77, :111-112, :124). The order is replayed by UMapOrder on the keys' hashes (umap_order.h) — no strings, no nodes.
-void CNVCaller::assembleRegion(const RegionBatch &B, size_t i, SNPData &d) const
+// Appends region i's observations to `out` (and closes its entry in out.off).
+void CNVCaller::assembleRegion(const RegionBatch &B, size_t i, ObsChunk &out) const
 {
-    if (B.slot[i] == SIZE_MAX) return;
-    const uint64_t w0 = B.win_off[B.slot[i]], w1 = B.win_off[B.slot[i] + 1];
-    static thread_local csvhost::UMapOrder order;
-    static thread_local std::vector<uint64_t> first_w, last_w;            // by node: the window that created the key / that wrote it last
-    order.clear(); first_w.clear(); last_w.clear();
-    for (uint64_t w = w0; w < w1; w++) {
-        char key[24];
-        char *e = std::to_chars(key, key + 11, B.ws[w]).ptr;
-        *e++ = '-';
-        e = std::to_chars(e, e + 11, B.we[w]).ptr;
-        const uint64_t h = csvhost::std_string_hash(key, (size_t)(e - key));
-        const int64_t node = order.find(h, [&](uint32_t nd) { return B.ws[first_w[nd]] == B.ws[w] && B.we[first_w[nd]] == B.we[w]; });
-        if (node >= 0) { last_w[(size_t)node] = w; continue; }
-        order.insert_new(h);
-        first_w.push_back(w); last_w.push_back(w);
-    }
-    const RegionBatch::RegionSnps &r = B.rs[i];
-    const size_t guess = order.size() + r.pos.size();
-    d.pos.reserve(guess); d.baf.reserve(guess); d.pfb.reserve(guess); d.log2_cov.reserve(guess); d.is_snp.reserve(guess);
-    order.for_each([&](uint32_t node) {
-        const uint32_t window_start = B.ws[first_w[node]], window_end = B.we[first_w[node]];
-        const double l2 = B.log2_cov[last_w[node]];
-        bool snp_found = false;
-        for (uint32_t pos : r.pos) {
-            if (pos >= window_start && pos <= window_end) {        // inclusive both ends: a SNP can land in two windows (:132)
-                const auto b = r.baf.find(pos), f = r.pfb.find(pos);
-                d.pos.push_back(pos); d.baf.push_back(b != r.baf.end() ? b->second : 0.0); d.pfb.push_back(f != r.pfb.end() ? f->second : 0.0);   // operator[]: 0.0 when absent (:138)
-                d.log2_cov.push_back(l2); d.is_snp.push_back(true);
-                snp_found = true;
+    if (B.slot[i] != SIZE_MAX) {
+        const uint64_t w0 = B.win_off[B.slot[i]], w1 = B.win_off[B.slot[i] + 1];
+        static thread_local csvhost::UMapOrder order;
+        static thread_local std::vector<uint64_t> first_w, last_w;            // by node: the window that created the key / that wrote it last
+        order.clear(); first_w.clear(); last_w.clear();
+        for (uint64_t w = w0; w < w1; w++) {
+            char key[24];
+            char *e = std::to_chars(key, key + 11, B.ws[w]).ptr;
+            *e++ = '-';
+            e = std::to_chars(e, e + 11, B.we[w]).ptr;
+            const uint64_t h = csvhost::std_string_hash(key, (size_t)(e - key));
+            const int64_t node = order.find(h, [&](uint32_t nd) { return B.ws[first_w[nd]] == B.ws[w] && B.we[first_w[nd]] == B.we[w]; });
+            if (node >= 0) { last_w[(size_t)node] = w; continue; }
+            order.insert_new(h);
+            first_w.push_back(w); last_w.push_back(w);
+        }
+        const SnpChunk &sc = B.snp[i / kChunk];
+        const uint32_t s0 = sc.off[i % kChunk], s1 = sc.off[i % kChunk + 1];
+        order.for_each([&](uint32_t node) {
+            const uint32_t window_start = B.ws[first_w[node]], window_end = B.we[first_w[node]];
+            const double l2 = B.log2_cov[last_w[node]];
+            bool snp_found = false;
+            for (uint32_t k = s0; k < s1; k++) {
+                const uint32_t pos = sc.pos[k];
+                if (pos >= window_start && pos <= window_end) {        // inclusive both ends: a SNP can land in two windows (:132)
+                    out.pos.push_back(pos); out.baf.push_back(sc.baf[k]); out.pfb.push_back(sc.pfb[k]);
+                    out.l2.push_back(l2); out.is_snp.push_back(1);
+                    snp_found = true;
+                }
             }
-        }
-        if (!snp_found) {                                           // dummy observation at the window centre (:144-155)
-            d.pos.push_back((window_start + window_end) / 2); d.baf.push_back(-1.0); d.pfb.push_back(0.5);
-            d.log2_cov.push_back(l2); d.is_snp.push_back(false);
-        }
-    });
+            if (!snp_found) {                                           // dummy observation at the window centre (:144-155)
+                out.pos.push_back((window_start + window_end) / 2); out.baf.push_back(-1.0); out.pfb.push_back(0.5);
+                out.l2.push_back(l2); out.is_snp.push_back(0);
+            }
+        });
+    }
+    out.off.push_back(out.pos.size());
 }
 
 void CNVCaller::querySNPRegions(const std::vector<std::pair<uint32_t, uint32_t>> &regions, csv_shard *shard, double mean_chr_cov,
@@ -136,53 +189,88 @@ void CNVCaller::querySNPRegions(const std::vector<std::pair<uint32_t, uint32_t>>
     prepareWindows(B, snps);
     launchWindows(B, shard, mean_chr_cov);
     out.assign(regions.size(), SNPData());
-    csvhost::parallel_for(regions.size(), host_threads, [&](size_t i) { assembleRegion(B, i, out[i]); });
-}
-
-// all sequences of `data` through ONE Viterbi launch; states come back flat (sequence q = [seq_off[q], seq_off[q + 1]))
-void CNVCaller::runViterbiFlat(const CHMM &hmm, const std::vector<const SNPData *> &data, std::vector<uint64_t> &seq_off, std::vector<int> &states,
-                               std::vector<double> &loglik) const
-{
-    const size_t n = data.size();
-    seq_off.assign(n + 1, 0);
-    for (size_t q = 0; q < n; q++) seq_off[q + 1] = seq_off[q] + data[q]->pos.size();
-    VitBatch b;
-    b.o1.resize(seq_off[n]); b.o2.resize(seq_off[n]); b.pfb.resize(seq_off[n]);
-    b.seq_off = seq_off;
-    csvhost::parallel_for(n, host_threads, [&](size_t q) {
-        const SNPData &d = *data[q];
-        std::copy(d.log2_cov.begin(), d.log2_cov.end(), b.o1.begin() + (std::ptrdiff_t)seq_off[q]);
-        std::copy(d.baf.begin(), d.baf.end(), b.o2.begin() + (std::ptrdiff_t)seq_off[q]);
-        std::copy(d.pfb.begin(), d.pfb.end(), b.pfb.begin() + (std::ptrdiff_t)seq_off[q]);
+    csvhost::parallel_for(regions.size(), host_threads, [&](size_t i) {
+        ObsChunk o;
+        assembleRegion(B, i, o);
+        SNPData &d = out[i];
+        d.pos = std::move(o.pos); d.baf = std::move(o.baf); d.pfb = std::move(o.pfb); d.log2_cov = std::move(o.l2);
+        d.is_snp.assign(o.is_snp.begin(), o.is_snp.end());
     });
-    testVit_CHMM_batch(hmm, b, states, loglik);
-    for (size_t q = 0; q < n; q++)
-        if (data[q]->pos.empty()) printError("ERROR: No SNP data found for Viterbi algorithm.");      // runViterbi logs and still calls testVit_CHMM with T = 0 (:43-49)
 }
 
 void CNVCaller::runViterbi(const CHMM &hmm, const std::vector<SNPData> &data, std::vector<std::pair<std::vector<int>, double>> &predictions) const
 {
-    std::vector<const SNPData *> ptr(data.size());
-    for (size_t i = 0; i < data.size(); i++) ptr[i] = &data[i];
-    std::vector<uint64_t> off;
+    VitBatch b;
+    for (const SNPData &d : data) b.add(d.log2_cov, d.baf, d.pfb);
     std::vector<int> states;
     std::vector<double> ll;
-    runViterbiFlat(hmm, ptr, off, states, ll);
+    testVit_CHMM_batch(hmm, b, states, ll);
     predictions.resize(data.size());
-    for (size_t i = 0; i < data.size(); i++)
-        predictions[i] = std::make_pair(std::vector<int>(states.begin() + (std::ptrdiff_t)off[i], states.begin() + (std::ptrdiff_t)off[i + 1]), ll[i]);
+    for (size_t i = 0; i < data.size(); i++) {
+        if (data[i].pos.empty()) printError("ERROR: No SNP data found for Viterbi algorithm.");      // runViterbi logs and still calls testVit_CHMM with T = 0 (:43-49)
+        predictions[i] = std::make_pair(std::vector<int>(states.begin() + (std::ptrdiff_t)b.seq_off[i], states.begin() + (std::ptrdiff_t)b.seq_off[i + 1]), ll[i]);
+    }
 }
 
-// cnv_caller.cpp:337-384 for one candidate given its observations and state path
-void CNVCaller::applyCIGARPrediction(const std::string &chr, SVCall &sv_call, const SNPData &snp_data, const int *state_sequence, size_t T, double likelihood) const
+// Observation vectors of ALL candidates of a genome-wide pass (chunked over the pool) and ONE Viterbi launch over them.
+struct CNVCaller::GenomeObs {
+    struct Cand { size_t job, call, region; };
+    std::vector<Cand> cands;
+    std::vector<ObsChunk> chunks;              // candidate q: chunk q / kChunk, entry q % kChunk
+    std::vector<uint64_t> seq_off;             // candidate q's observations in the flat Viterbi batch
+    std::vector<int> states;
+    std::vector<double> ll;
+    const uint32_t *pos(size_t q) const { const ObsChunk &c = chunks[q / kChunk]; return c.pos.data() + c.off[q % kChunk]; }
+    size_t len(size_t q) const { return (size_t)(seq_off[q + 1] - seq_off[q]); }
+};
+
+void CNVCaller::observeAndDecode(std::vector<RegionBatch> &batches, const std::vector<ContigJob> &jobs, const CHMM &hmm, GenomeObs &G) const
 {
-    if (snp_data.pos.empty()) {
+    {
+        csvhost::TraceScope tr("cn: snp queries");
+        for (size_t j = 0; j < jobs.size(); j++) if (!batches[j].regions.empty()) prepareWindows(batches[j], *jobs[j].snps);
+    }
+    {
+        csvhost::TraceScope tr("cn: window launches");
+        for (size_t j = 0; j < jobs.size(); j++) if (!batches[j].regions.empty()) launchWindows(batches[j], jobs[j].shard, jobs[j].mean_chr_cov);
+    }
+    const size_t n = G.cands.size();
+    G.chunks.assign((n + kChunk - 1) / kChunk, ObsChunk());
+    {
+        csvhost::TraceScope tr("cn: assemble");
+        csvhost::parallel_for(G.chunks.size(), host_threads, [&](size_t c) {
+            for (size_t q = c * kChunk; q < std::min(n, (c + 1) * kChunk); q++) assembleRegion(batches[G.cands[q].job], G.cands[q].region, G.chunks[c]);
+        });
+    }
+    csvhost::TraceScope tr("cn: viterbi");
+    VitBatch b;
+    b.seq_off.assign(n + 1, 0);
+    std::vector<uint64_t> chunk_base(G.chunks.size() + 1, 0);
+    for (size_t c = 0; c < G.chunks.size(); c++) chunk_base[c + 1] = chunk_base[c] + G.chunks[c].pos.size();
+    b.o1.resize(chunk_base.back()); b.o2.resize(chunk_base.back()); b.pfb.resize(chunk_base.back());
+    csvhost::parallel_for(G.chunks.size(), host_threads, [&](size_t c) {
+        const ObsChunk &ch = G.chunks[c];
+        std::copy(ch.l2.begin(), ch.l2.end(), b.o1.begin() + (std::ptrdiff_t)chunk_base[c]);
+        std::copy(ch.baf.begin(), ch.baf.end(), b.o2.begin() + (std::ptrdiff_t)chunk_base[c]);
+        std::copy(ch.pfb.begin(), ch.pfb.end(), b.pfb.begin() + (std::ptrdiff_t)chunk_base[c]);
+        for (size_t k = 0; k + 1 < ch.off.size(); k++) b.seq_off[c * kChunk + k + 1] = chunk_base[c] + ch.off[k + 1];
+    });
+    testVit_CHMM_batch(hmm, b, G.states, G.ll);
+    G.seq_off = b.seq_off;
+    for (size_t q = 0; q < n; q++)
+        if (G.len(q) == 0) printError("ERROR: No SNP data found for Viterbi algorithm.");              // runViterbi logs and still calls testVit_CHMM with T = 0 (:43-49)
+}
+
+// cnv_caller.cpp:337-384 for one candidate given its observation positions and state path
+void CNVCaller::applyCIGARPrediction(const std::string &chr, SVCall &sv_call, const uint32_t *obs_pos, const int *state_sequence, size_t T, double likelihood) const
+{
+    if (T == 0) {
         printError("ERROR: No SNP data found for Viterbi algorithm for CIGAR SV at " + chr + ":" + std::to_string((int)sv_call.start) + "-" + std::to_string((int)sv_call.end));
         return;
     }
     int counts[7] = {0, 0, 0, 0, 0, 0, 0}, n_in = 0;                // states of observations inside [start,end] (:337-346)
     for (size_t i = 0; i < T; i++)
-        if (snp_data.pos[i] >= sv_call.start && snp_data.pos[i] <= sv_call.end) { counts[state_sequence[i]]++; n_in++; }
+        if (obs_pos[i] >= sv_call.start && obs_pos[i] <= sv_call.end) { counts[state_sequence[i]]++; n_in++; }
     int max_state = 0, max_count = 0;                                // first maximum wins (:350-360)
     for (int s = 1; s <= 6; s++) if (counts[s] > max_count) { max_state = s; max_count = counts[s]; }
     if ((double)max_count / (double)n_in < 0.50) max_state = 0;      // :363-367 (0/0 -> NaN < 0.5 is false, as in the reference)
@@ -210,8 +298,7 @@ size_t CNVCaller::runCIGARCopyNumberPrediction(const std::string &chr, std::vect
 // vectors of ALL candidates assembled on the host pool, ONE Viterbi launch, the votes on the pool.
 size_t CNVCaller::runCIGARCopyNumberPredictionAll(std::vector<ContigJob> &jobs, const CHMM &hmm) const
 {
-    struct Cand { size_t job, call, region; };
-    std::vector<Cand> cands;
+    GenomeObs G;
     std::vector<RegionBatch> batches(jobs.size());
     for (size_t j = 0; j < jobs.size(); j++) {
         std::vector<SVCall> &v = *jobs[j].calls;
@@ -222,28 +309,18 @@ size_t CNVCaller::runCIGARCopyNumberPredictionAll(std::vector<ContigJob> &jobs, 
                 continue;
             }
             if ((c.end - c.start) < min_cnv_length) continue;               // :315
-            cands.push_back(Cand{j, k, batches[j].regions.size()});
+            G.cands.push_back(GenomeObs::Cand{j, k, batches[j].regions.size()});
             batches[j].regions.emplace_back(c.start, c.end);
         }
     }
-    if (cands.empty()) return 0;
-    for (size_t j = 0; j < jobs.size(); j++) {
-        if (batches[j].regions.empty()) continue;
-        prepareWindows(batches[j], *jobs[j].snps);
-        launchWindows(batches[j], jobs[j].shard, jobs[j].mean_chr_cov);
-    }
-    std::vector<SNPData> data(cands.size());
-    csvhost::parallel_for(cands.size(), host_threads, [&](size_t q) { assembleRegion(batches[cands[q].job], cands[q].region, data[q]); });
-    std::vector<const SNPData *> ptr(cands.size());
-    for (size_t q = 0; q < cands.size(); q++) ptr[q] = &data[q];
-    std::vector<uint64_t> off;
-    std::vector<int> states;
-    std::vector<double> ll;
-    runViterbiFlat(hmm, ptr, off, states, ll);
-    csvhost::parallel_for(cands.size(), host_threads, [&](size_t q) {
-        applyCIGARPrediction(jobs[cands[q].job].chr, (*jobs[cands[q].job].calls)[cands[q].call], data[q], states.data() + off[q], (size_t)(off[q + 1] - off[q]), ll[q]);
+    if (G.cands.empty()) return 0;
+    observeAndDecode(batches, jobs, hmm, G);
+    csvhost::TraceScope tr("cn: votes");
+    csvhost::parallel_for(G.chunks.size(), host_threads, [&](size_t c) {
+        for (size_t q = c * kChunk; q < std::min(G.cands.size(), (c + 1) * kChunk); q++)
+            applyCIGARPrediction(jobs[G.cands[q].job].chr, (*jobs[G.cands[q].job].calls)[G.cands[q].call], G.pos(q), G.states.data() + G.seq_off[q], G.len(q), G.ll[q]);
     });
-    return cands.size();
+    return G.cands.size();
 }
 
 // cnv_caller.cpp:214-238: the state a split-read region is given from its path: the largest non-neutral share if above 0.3, else
@@ -393,8 +470,7 @@ void CNVCaller::runSplitReadCopyNumberPredictionsAll(std::vector<ContigJob> &job
         for (ContigJob &j : jobs) runSplitReadCopyNumberPredictions(j.chr, *j.calls, hmm, j.mean_chr_cov, j.shard, *j.snps, j.depth_len);
         return;
     }
-    struct Cand { size_t job, call, region; };
-    std::vector<Cand> cands;
+    GenomeObs G;
     std::vector<RegionBatch> batches(jobs.size());
     std::vector<std::vector<std::tuple<double, SVType, Genotype, int>>> results(jobs.size());
     for (size_t j = 0; j < jobs.size(); j++) {
@@ -405,29 +481,17 @@ void CNVCaller::runSplitReadCopyNumberPredictionsAll(std::vector<ContigJob> &job
                 printError("ERROR: Invalid SV region for copy number prediction: " + jobs[j].chr + ":" + std::to_string((int)v[k].start) + "-" + std::to_string((int)v[k].end));
                 continue;
             }
-            cands.push_back(Cand{j, k, batches[j].regions.size()});
+            G.cands.push_back(GenomeObs::Cand{j, k, batches[j].regions.size()});
             batches[j].regions.emplace_back(v[k].start, v[k].end);
         }
     }
-    if (!cands.empty()) {
-        for (size_t j = 0; j < jobs.size(); j++) {
-            if (batches[j].regions.empty()) continue;
-            prepareWindows(batches[j], *jobs[j].snps);
-            launchWindows(batches[j], jobs[j].shard, jobs[j].mean_chr_cov);
-        }
-        std::vector<SNPData> data(cands.size());
-        csvhost::parallel_for(cands.size(), host_threads, [&](size_t q) { assembleRegion(batches[cands[q].job], cands[q].region, data[q]); });
-        std::vector<const SNPData *> ptr(cands.size());
-        for (size_t q = 0; q < cands.size(); q++) ptr[q] = &data[q];
-        std::vector<uint64_t> off;
-        std::vector<int> states;
-        std::vector<double> ll;
-        runViterbiFlat(hmm, ptr, off, states, ll);
-        for (size_t q = 0; q < cands.size(); q++) {
-            const size_t T = (size_t)(off[q + 1] - off[q]);
+    if (!G.cands.empty()) {
+        observeAndDecode(batches, jobs, hmm, G);
+        for (size_t q = 0; q < G.cands.size(); q++) {
+            const size_t T = G.len(q);
             if (T == 0) continue;                                         // :206-209
-            const int max_state = splitVote(states.data() + off[q], T);
-            results[cands[q].job][cands[q].call] = std::make_tuple(ll[q], getSVTypeFromCNState(max_state), getGenotypeFromCNState(max_state), max_state);
+            const int max_state = splitVote(G.states.data() + G.seq_off[q], T);
+            results[G.cands[q].job][G.cands[q].call] = std::make_tuple(G.ll[q], getSVTypeFromCNState(max_state), getGenotypeFromCNState(max_state), max_state);
         }
     }
     for (size_t j = 0; j < jobs.size(); j++) applySplitPredictions(*jobs[j].calls, results[j]);

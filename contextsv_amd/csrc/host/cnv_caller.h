@@ -34,6 +34,10 @@ struct SNPSource {
     virtual ~SNPSource() = default;
     virtual void query(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos,
                        std::unordered_map<uint32_t, double> &snp_baf, std::unordered_map<uint32_t, double> &snp_pfb) const = 0;
+    // The same result without the maps, APPENDED to the three vectors: positions in the order query() gives them, and for each the
+    // value snp_baf[pos] / snp_pfb[pos] would hold after query() (pfb: 0.0 where the map has no entry). Default: through query().
+    virtual void queryFlat(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos, std::vector<double> &baf_at,
+                           std::vector<double> &pfb_at) const;
 };
 
 // SNPs of one chromosome held in sorted arrays (the one-time-per-chromosome load the reference lacks).
@@ -44,6 +48,8 @@ struct SNPTable : SNPSource {
     std::vector<uint8_t> has_pfb;
     void query(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos, std::unordered_map<uint32_t, double> &snp_baf,
                std::unordered_map<uint32_t, double> &snp_pfb) const override;
+    void queryFlat(uint32_t start_pos, uint32_t end_pos, std::vector<uint32_t> &snp_pos, std::vector<double> &baf_at,
+                   std::vector<double> &pfb_at) const override;
 };
 
 class CNVCaller {
@@ -102,12 +108,14 @@ public:
 private:
     csv_ctx *ctx;
     struct RegionBatch;
+    struct SnpChunk;
+    struct ObsChunk;
+    struct GenomeObs;
     void prepareWindows(RegionBatch &B, const SNPSource &snps) const;
     void launchWindows(RegionBatch &B, csv_shard *shard, double mean_chr_cov) const;
-    void assembleRegion(const RegionBatch &B, size_t i, SNPData &d) const;
-    void runViterbiFlat(const CHMM &hmm, const std::vector<const SNPData *> &data, std::vector<uint64_t> &seq_off, std::vector<int> &states,
-                        std::vector<double> &loglik) const;
-    void applyCIGARPrediction(const std::string &chr, SVCall &sv_call, const SNPData &snp_data, const int *state_sequence, size_t T, double likelihood) const;
+    void assembleRegion(const RegionBatch &B, size_t i, ObsChunk &out) const;
+    void observeAndDecode(std::vector<RegionBatch> &batches, const std::vector<ContigJob> &jobs, const CHMM &hmm, GenomeObs &G) const;
+    void applyCIGARPrediction(const std::string &chr, SVCall &sv_call, const uint32_t *obs_pos, const int *state_sequence, size_t T, double likelihood) const;
     static int splitVote(const int *seq, size_t T);
     static void applySplitPredictions(std::vector<SVCall> &split_sv_calls, const std::vector<std::tuple<double, SVType, Genotype, int>> &results);
 };

@@ -4,15 +4,28 @@
 // writes only its own slot. The reference's counterpart is its ThreadPool over chromosomes (include/ThreadPool.h, sv_caller.cpp:827-863).
 #pragma once
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstddef>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
 
 namespace csvhost {
+
+// CSV_TRACE=1 in the environment: wall time of named sections to stderr (where a whole-genome step's host time goes)
+struct TraceScope {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    static bool on() { static const bool v = [] { const char *e = getenv("CSV_TRACE"); return e && *e && *e != '0'; }(); return v; }
+    explicit TraceScope(const char *n) : name(n) { if (on()) t0 = std::chrono::steady_clock::now(); }
+    ~TraceScope() { if (on()) fprintf(stderr, "[csv trace] %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
 
 class HostPool {
 public:
@@ -24,6 +37,7 @@ public:
 
     // f(i) for every i in [0, n), on up to `threads` threads (0: all of the pool's), the caller's included; returns when all are done.
     // Items are handed out one at a time in index order (put the heavy ones first). The first exception is rethrown here.
+    // A section is over when its last ITEM is done, not when every worker has woken up: a worker that arrives late finds nothing left.
     template <class F>
     void parallel_for(size_t n, int threads, F &&f)
     {
@@ -36,24 +50,28 @@ public:
             if (mine) busy_ = false;
             return;
         }
-        Job job;
-        job.n = n;
-        job.fn = [&](size_t i) { f(i); };
+        std::shared_ptr<Job> job = std::make_shared<Job>();
+        job->n = n;
+        job->fn = [&](size_t i) { f(i); };
         {
             std::lock_guard<std::mutex> l(mu_);
-            job_ = &job;
+            job_ = job;
             want_ = T - 1;
             generation_++;
         }
-        cv_.notify_all();
-        run(job);
+        if (T - 1 >= workers_.size()) cv_.notify_all();
+        else for (size_t k = 0; k + 1 < T; k++) cv_.notify_one();
+        run(*job);
         {
-            std::unique_lock<std::mutex> l(mu_);
-            done_cv_.wait(l, [&] { return job.active == 0 && job.entered == want_; });
-            job_ = nullptr;
+            std::unique_lock<std::mutex> l(job->done_mu);
+            job->done_cv.wait(l, [&] { return job->done.load(std::memory_order_acquire) == n; });
+        }
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            job_.reset();
         }
         busy_ = false;
-        if (job.err) std::rethrow_exception(job.err);
+        if (job->err) std::rethrow_exception(job->err);
     }
 
     size_t size() const { return workers_.size() + 1; }
@@ -61,19 +79,21 @@ public:
 private:
     struct Job {
         size_t n = 0;
-        std::function<void(size_t)> fn;
-        std::atomic<size_t> next{0};
-        size_t active = 0, entered = 0;                          // guarded by mu_
+        std::function<void(size_t)> fn;                          // refers to the caller's frame: only called for items, and the caller waits for every item
+        std::atomic<size_t> next{0}, done{0};
         std::exception_ptr err;
-        std::mutex err_mu;
+        std::mutex err_mu, done_mu;
+        std::condition_variable done_cv;
     };
 
     HostPool()
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t n = hw ? hw : 4;
-        if (n > 32) n = 32;                                      // the CPU share of one GPU on the boxes this runs on is 16
-        for (size_t t = 1; t < n; t++) workers_.emplace_back([this, t] { loop(t); });
+        // CSV_HOST_THREADS, else the hardware's count capped at 16: the CPU share of one GPU on the boxes this runs on
+        size_t n = 0;
+        if (const char *e = getenv("CSV_HOST_THREADS")) n = (size_t)atoi(e);
+        if (n == 0) { const unsigned hw = std::thread::hardware_concurrency(); n = hw ? hw : 4; if (n > 16) n = 16; }
+        if (n > 256) n = 256;
+        for (size_t t = 1; t < n; t++) workers_.emplace_back([this] { loop(); });
     }
     ~HostPool()
     {
@@ -82,43 +102,42 @@ private:
         for (auto &w : workers_) w.join();
     }
 
-    void run(Job &job)
+    static void run(Job &job)
     {
+        size_t mine = 0;
         for (size_t i; (i = job.next.fetch_add(1, std::memory_order_relaxed)) < job.n;) {
             try { job.fn(i); } catch (...) {
                 std::lock_guard<std::mutex> l(job.err_mu);
                 if (!job.err) job.err = std::current_exception();
             }
+            mine++;
+        }
+        if (mine && job.done.fetch_add(mine, std::memory_order_acq_rel) + mine == job.n) {
+            std::lock_guard<std::mutex> l(job.done_mu);
+            job.done_cv.notify_all();
         }
     }
 
-    void loop(size_t id)
+    void loop()
     {
         size_t seen = 0;
         for (;;) {
-            Job *job = nullptr;
+            std::shared_ptr<Job> job;
             {
                 std::unique_lock<std::mutex> l(mu_);
                 cv_.wait(l, [&] { return stop_ || generation_ != seen; });
                 if (stop_) return;
                 seen = generation_;
-                if (!job_ || id > want_) continue;               // this section wants fewer threads
                 job = job_;
-                job->active++; job->entered++;
             }
-            run(*job);
-            {
-                std::lock_guard<std::mutex> l(mu_);
-                job->active--;
-            }
-            done_cv_.notify_all();
+            if (job) run(*job);
         }
     }
 
     std::vector<std::thread> workers_;
     std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
-    Job *job_ = nullptr;
+    std::condition_variable cv_;
+    std::shared_ptr<Job> job_;
     size_t want_ = 0, generation_ = 0;
     bool stop_ = false;
     std::atomic<bool> busy_{false};

@@ -142,7 +142,7 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
                            std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
 {
     for (const SplitContig &c : contigs)
-        if (c.n && (!c.qhash || (!c.name_id && !(c.name_bytes && c.name_off)) || (!c.intervals && !(c.ref_end && c.q_start && c.q_end))))
+        if (c.n && (!c.qhash || (!c.name_id && !(c.name_bytes && c.name_off)) || (!params.intervals && !(c.ref_end && c.q_start && c.q_end))))
             throw std::runtime_error("findSplitSVSignatures: a contig without query-name hashes / identities or without alignment intervals");
     // larger contigs first: the wall time of a parallel phase is the largest contig's
     std::vector<size_t> by_size(contigs.size());
@@ -159,6 +159,7 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     // Contigs whose names are known to be unique can get the map's iteration order from params.device_order (the device): for them
     // only the supplementary records are collected here and the primaries counted.
     auto on_device = [&](size_t c) { return params.device_order && contigs[c].unique_names; };
+    std::unique_ptr<csvhost::TraceScope> tr(new csvhost::TraceScope("split: collect"));
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         const size_t c = by_size[k];
         ContigWork &W = work[c];
@@ -180,11 +181,13 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     });
 
     // ---- supp_map: every supplementary record of the run by name, file order within a name (:162-165) ---------------------------
+    tr.reset(new csvhost::TraceScope("split: supp index"));
     std::vector<SuppRef> supp_index;
     for (const ContigWork &W : work) supp_index.insert(supp_index.end(), W.supps.begin(), W.supps.end());
     std::sort(supp_index.begin(), supp_index.end(), [](const SuppRef &a, const SuppRef &b) { return a.hash != b.hash ? a.hash < b.hash : a.ord < b.ord; });
 
     // ---- the device's share: which primaries have a supplementary record's name hash, in the map's iteration order ----------------
+    tr.reset(new csvhost::TraceScope("split: device order"));
     std::vector<size_t> dev_contigs;
     std::vector<std::vector<uint32_t>> dev_recs;
     for (size_t c = 0; c < contigs.size(); c++) if (on_device(c) && work[c].n_primary) dev_contigs.push_back(c);
@@ -197,6 +200,7 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     }
 
     // ---- survivors (primaries with a supplementary record, :183-202) in the map's iteration order, with their supplementary records ----
+    tr.reset(new csvhost::TraceScope("split: survivors"));
     std::atomic<long> total_removed{0};
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         ContigWork &W = work[by_size[k]];
@@ -219,15 +223,33 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
 
     // ---- the alignment intervals of the records that are left (ref_end / q_start / q_end of the scan kernel): straight from the
     // arrays, or — contigs that carry an IntervalSource — gathered for just these records (a few per cent of the contig's) ----------
-    for (ContigWork &W : work) {
-        const SplitContig &C = *W.in;
-        if (C.ref_end || !C.intervals) continue;
-        for (uint32_t r : W.member_rec) W.need.push_back(r);
-        for (const SuppRef &sr : W.supps) W.need.push_back(sr.rec);
-        std::sort(W.need.begin(), W.need.end());
-        W.need.erase(std::unique(W.need.begin(), W.need.end()), W.need.end());
-        for (int a = 0; a < 3; a++) W.got[a].resize(W.need.size());
-        if (!W.need.empty()) C.intervals->gather(W.need.data(), W.need.size(), W.got[0].data(), W.got[1].data(), W.got[2].data());
+    tr.reset(new csvhost::TraceScope("split: interval gather"));
+    {
+        std::vector<size_t> which;
+        std::vector<uint32_t> rec;
+        std::vector<uint64_t> rec_off{0};
+        for (size_t c = 0; c < work.size(); c++) {
+            ContigWork &W = work[c];
+            if (W.in->ref_end) continue;
+            for (uint32_t r : W.member_rec) W.need.push_back(r);
+            for (const SuppRef &sr : W.supps) W.need.push_back(sr.rec);
+            std::sort(W.need.begin(), W.need.end());
+            W.need.erase(std::unique(W.need.begin(), W.need.end()), W.need.end());
+            if (W.need.empty()) continue;
+            which.push_back(c);
+            rec.insert(rec.end(), W.need.begin(), W.need.end());
+            rec_off.push_back(rec.size());
+        }
+        if (!which.empty()) {
+            std::vector<int32_t> a(rec.size()), b(rec.size()), d(rec.size());
+            params.intervals->gather(which, rec, rec_off, a.data(), b.data(), d.data());
+            for (size_t k = 0; k < which.size(); k++) {
+                ContigWork &W = work[which[k]];
+                W.got[0].assign(a.begin() + (std::ptrdiff_t)rec_off[k], a.begin() + (std::ptrdiff_t)rec_off[k + 1]);
+                W.got[1].assign(b.begin() + (std::ptrdiff_t)rec_off[k], b.begin() + (std::ptrdiff_t)rec_off[k + 1]);
+                W.got[2].assign(d.begin() + (std::ptrdiff_t)rec_off[k], d.begin() + (std::ptrdiff_t)rec_off[k + 1]);
+            }
+        }
     }
     auto interval = [&](const ContigWork &W, uint32_t rec, int which) -> int32_t {
         const SplitContig &C = *W.in;
@@ -237,6 +259,7 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     };
 
     // ---- phase 2: interval tree, overlap groups, the six point sets (:215-347), per contig ---------------------------------------
+    tr.reset(new csvhost::TraceScope("split: groups"));
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         ContigWork &W = work[by_size[k]];
         const SplitContig &C = *W.in;
@@ -305,6 +328,7 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     printMessage("Removed " + std::to_string(total_removed.load()) + " primary alignments without supplementary alignments");
 
     // ---- the six DBSCAN1D(100, 5) fits of every group of every contig: ONE batched launch (:270-372) ------------------------------
+    tr.reset(new csvhost::TraceScope("split: dbscan1d batch"));
     std::vector<std::vector<int>> flat_sets, flat_labels;
     for (ContigWork &W : work) {
         W.set_base = flat_sets.size();
@@ -313,6 +337,7 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     if (!flat_sets.empty()) DBSCAN1D::fitBatch(flat_sets, params.eps, params.min_pts, flat_labels);
 
     // ---- phase 3: medians, SPLITDIST1 candidates, SPLIT dummies (:283-486), per contig --------------------------------------------
+    tr.reset(new csvhost::TraceScope("split: calls"));
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         ContigWork &W = work[by_size[k]];
         if (W.n_primary == 0) return;                        // no entry in primary_map for this tid
@@ -384,6 +409,7 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
         });
         mergeDuplicateSVs(chr_sv_calls);
     });
+    tr.reset();
     for (ContigWork &W : work) {
         if (W.n_primary == 0) continue;
         const std::string chr_name = target_names.at((size_t)W.in->tid);

@@ -27,6 +27,17 @@ struct SplitRecord {
     int32_t  q_end;      // query_end            }  or csvgpu_aln_intervals)
 };
 
+// Where the scan kernel's per-record intervals come from when they are not handed over as whole arrays: only the records that take
+// part in a group (primaries with a supplementary record, and those records) are ever asked for — a few per cent of a contig — and
+// for all contigs in one request.
+struct IntervalSource {
+    virtual ~IntervalSource() = default;
+    // contig which[k] (index into the `contigs` vector): records rec[rec_off[k] .. rec_off[k+1]) (ascending, distinct) -> their
+    // ref_end / q_start / q_end at the same positions of the three outputs
+    virtual void gather(const std::vector<size_t> &which, const std::vector<uint32_t> &rec, const std::vector<uint64_t> &rec_off,
+                        int32_t *ref_end, int32_t *q_start, int32_t *q_end) const = 0;
+};
+
 // The surviving primaries of several contigs, each in the iteration order of the reference's per-chromosome qname map, computed
 // somewhere else than on this host thread (the device: csvgpu_split_order behind ShardOrderSource in sv_caller.cpp).
 struct SplitOrderSource {
@@ -42,16 +53,9 @@ struct SplitParams {
     int min_pts = 5;
     int min_length = 2000;    // :243
     int max_length = 1000000; // :244
+    const IntervalSource *intervals = nullptr;        // for contigs given without ref_end / q_start / q_end arrays
     const SplitOrderSource *device_order = nullptr;   // where contigs with unique_names get their iteration order from (nullptr: replayed on the host)
     int threads = 0;          // host threads over contigs (0: one per contig, at most the hardware's); the result does not depend on it
-};
-
-// Where the scan kernel's per-record intervals come from when they are not handed over as whole arrays: only the records that take
-// part in a group (primaries with a supplementary record, and those records) are ever asked for — a few per cent of a contig.
-struct IntervalSource {
-    virtual ~IntervalSource() = default;
-    // ref_end / q_start / q_end of records rec[0..n) (ascending, distinct)
-    virtual void gather(const uint32_t *rec, size_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end) const = 0;
 };
 
 // The records of one contig (one tid), struct of arrays, file order — what a decoded shard holds on the host plus the scan
@@ -64,8 +68,7 @@ struct SplitContig {
     const int32_t *pos = nullptr;
     const uint16_t *flag = nullptr;
     const uint8_t *mapq = nullptr;
-    const int32_t *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr;   // whole arrays, or ...
-    const IntervalSource *intervals = nullptr;                               // ... a source asked for the few records that matter
+    const int32_t *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr;   // whole arrays, or null: SplitParams::intervals is asked for the few records that matter
     const uint64_t *qhash = nullptr;
     const uint64_t *name_id = nullptr;
     const char *name_bytes = nullptr;

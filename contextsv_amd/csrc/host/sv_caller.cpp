@@ -315,15 +315,19 @@ void SVCaller::processChromosome(const std::string &chr, const csv_reads &reads,
 
 
 namespace {
-// alignment intervals of selected records of a resident shard (csvgpu_aln_intervals_gather_resident)
+// alignment intervals of selected records of resident shards (csvgpu_aln_intervals_gather_batch): shard_of[c] is the resident shard of
+// split-pass contig c
 struct ShardIntervals : IntervalSource {
-    ShardIntervals(csv_ctx *ctx, csv_shard *shard) : ctx(ctx), shard(shard) {}
-    void gather(const uint32_t *rec, size_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end) const override
+    ShardIntervals(csv_ctx *ctx, std::vector<csv_shard *> shard_of) : ctx(ctx), shard_of(std::move(shard_of)) {}
+    void gather(const std::vector<size_t> &which, const std::vector<uint32_t> &rec, const std::vector<uint64_t> &rec_off, int32_t *ref_end, int32_t *q_start,
+                int32_t *q_end) const override
     {
-        check(ctx, csvgpu_aln_intervals_gather_resident(ctx, shard, rec, n, ref_end, q_start, q_end), "alignment intervals");
+        std::vector<csv_shard *> sh(which.size());
+        for (size_t k = 0; k < which.size(); k++) sh[k] = shard_of[which[k]];
+        check(ctx, csvgpu_aln_intervals_gather_batch(ctx, (int)sh.size(), sh.data(), rec.data(), rec_off.data(), ref_end, q_start, q_end), "alignment intervals");
     }
     csv_ctx *ctx;
-    csv_shard *shard;
+    std::vector<csv_shard *> shard_of;
 };
 
 // the iteration order of the reference's per-chromosome qname map from the device (csvgpu_split_order): shard_of[c] is the resident
@@ -520,15 +524,12 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         t0 = now_ms();
         // the scan kernel's per-read intervals (the reference's third BAM pass, :137-172) stay in the shards: the pass gathers the
         // few records it needs (ShardIntervals)
-        std::vector<std::unique_ptr<ShardIntervals>> sources;
         std::vector<SplitContig> blocks;
         for (size_t i = 0; i < contigs.size(); i++) {
             ResidentContig &c = contigs[i];
             if (!c.split.qhash || !c.shard || !c.split.n) continue;
-            sources.emplace_back(new ShardIntervals(ctx, c.shard));
             c.split.tid = (int32_t)i;
             c.split.ref_end = c.split.q_start = c.split.q_end = nullptr;
-            c.split.intervals = sources.back().get();
             blocks.push_back(c.split);
         }
         T.ms_split_fetch = now_ms() - t0;
@@ -538,6 +539,8 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         std::vector<csv_shard *> shard_of;
         for (const SplitContig &b : blocks) shard_of.push_back(contigs[(size_t)b.tid].shard);
         const ShardOrderSource dev_order(ctx, shard_of);
+        const ShardIntervals intervals(ctx, shard_of);
+        sp.intervals = &intervals;
         if (P.split_order_on_device) sp.device_order = &dev_order;                 // only contigs staged with unique_names take it
         findSplitSVSignatures(blocks, names, sp, split_calls);
         T.ms_split = now_ms() - t0;

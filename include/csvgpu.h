@@ -290,6 +290,9 @@ int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *shard, int32_t *ref_e
 /* The same for selected records only: ref_end[i] / q_start[i] / q_end[i] of record rec[i] (the split-read pass needs the intervals of
  * the primaries that have a supplementary record and of those records — a few per cent of a contig; sv_caller.cpp:152, :162). */
 int csvgpu_aln_intervals_gather_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *rec, uint64_t n, int32_t *ref_end, int32_t *q_start, int32_t *q_end);
+/* ... of several shards in one call: the records of shard c are rec[rec_off[c] .. rec_off[c+1]), outputs in the same layout. */
+int csvgpu_aln_intervals_gather_batch(csv_ctx *ctx, int n_shards, csv_shard *const *shards, const uint32_t *rec, const uint64_t *rec_off,
+                                      int32_t *ref_end, int32_t *q_start, int32_t *q_end);
 
 /* The query-name column of a resident shard: qname_hash[i] = std::hash<std::string> (libstdc++) of record i's query name — the value that
  * decides where the reference's unordered_map<std::string, PrimaryAlignment> puts the read (sv_caller.cpp:152). Copied to HBM, owned by the shard. */
