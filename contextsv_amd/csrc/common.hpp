@@ -195,6 +195,7 @@ void launch_iota_keys_u32(hipStream_t s, const uint32_t *k32, uint64_t n, uint64
 void launch_iota_keys_i32(hipStream_t s, const int32_t *k32, uint64_t n, uint64_t *keys, uint32_t *vals);   // order-preserving bias
 void launch_check_sorted_u32(hipStream_t s, const uint32_t *k, uint64_t n, unsigned int *flag);
 void launch_gather_u32(hipStream_t s, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst);
+void launch_gather3_u32(hipStream_t s, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *idx, uint64_t n, uint32_t *da, uint32_t *db, uint32_t *dc);
 void launch_exclusive_sum_u32(hipStream_t s, uint32_t *data, uint64_t n, void *tmp);   // in place
 size_t exclusive_sum_tmp_bytes(uint64_t n);
 // dbscan.hip
@@ -216,6 +217,7 @@ struct SplitOrderTab {                       // passed to the kernels by value
     uint64_t blk_off[SO_MAX_CONTIGS + 1];    // compaction: first 1024-record block of each contig
     uint64_t work_off[SO_MAX_CONTIGS + 1];   // epoch: first work item (node present in the epoch) of each active contig
     uint32_t nbase[SO_MAX_CONTIGS + 1];      // global index of each contig's first node
+    uint32_t m_old[SO_MAX_CONTIGS];          // epoch: nodes that were in the list when the epoch began (the rest were inserted during it)
     uint64_t n_reads[SO_MAX_CONTIGS];
     const uint16_t *flag[SO_MAX_CONTIGS];
     const uint8_t *mapq[SO_MAX_CONTIGS];
@@ -224,12 +226,12 @@ struct SplitOrderTab {                       // passed to the kernels by value
 struct csv_split_survivor { uint32_t contig, pos, rec; };
 void launch_so_count(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, uint32_t *blk_cnt);
 void launch_so_scatter(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, const uint32_t *blk_off, uint64_t *node_hash,
-                       uint32_t *node_rec, uint32_t *pos);
-void launch_so_mint(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, const uint64_t *node_hash, const uint32_t *pos, uint32_t *minT);
-void launch_so_keys(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, int w, const uint64_t *node_hash, const uint32_t *pos,
+                       uint32_t *node_rec);
+void launch_so_mint(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, const uint64_t *node_hash, const uint32_t *list, uint32_t *minT);
+void launch_so_keys(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, int w, const uint64_t *node_hash, const uint32_t *list,
                     const uint32_t *minT, uint64_t *keys, uint32_t *vals);
-void launch_so_setpos(hipStream_t s, const SplitOrderTab &tab, uint64_t M, const uint32_t *vals, uint32_t *pos);
-void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nodes, const uint64_t *node_hash, const uint32_t *node_rec, const uint32_t *pos,
+void launch_so_setlist(hipStream_t s, const SplitOrderTab &tab, uint64_t M, const uint32_t *vals, uint32_t *list);
+void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nodes, const uint64_t *node_hash, const uint32_t *node_rec, const uint32_t *list,
                          const uint64_t *supp_hash, uint64_t n_supp, csv_split_survivor *out, uint64_t cap, unsigned long long *count);
 // dbscan1d.hip
 void launch_dbscan_1d_batched(hipStream_t s, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg,

@@ -879,6 +879,80 @@ int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *sh, int32_t *ref_end,
     return CSV_OK;
 }
 
+int csvgpu_window_log2_resident_many(csv_ctx *ctx, int n_shards, csv_shard *const *shards, const uint32_t *const *region_start,
+                                     const uint32_t *const *region_end, const int32_t *const *sample_size, const uint64_t *const *win_off,
+                                     const uint64_t *n_regions, const double *mean_cov, double *const *log2_cov, uint32_t *const *win_start,
+                                     uint32_t *const *win_end)
+{
+    if (!ctx || n_shards < 0) return CSV_EINVAL;
+    if (n_shards == 0) return CSV_OK;
+    if (!shards || !region_start || !region_end || !sample_size || !win_off || !n_regions || !mean_cov || !log2_cov || !win_start || !win_end) {
+        ctx->err = "window_log2_many: null table"; return CSV_EINVAL;
+    }
+    uint64_t R = 0, W = 0;
+    for (int c = 0; c < n_shards; c++) {
+        const uint64_t nr = n_regions[c];
+        if (!nr) continue;
+        if (!shards[c] || !region_start[c] || !region_end[c] || !sample_size[c] || !win_off[c]) { ctx->err = "window_log2_many: null array"; return CSV_EINVAL; }
+        for (uint64_t r = 0; r < nr; r++)
+            if (sample_size[c][r] <= 0 || win_off[c][r + 1] - win_off[c][r] != (uint64_t)sample_size[c][r] || region_start[c][r] > region_end[c][r] || win_off[c][0] != 0) {
+                ctx->err = "window_log2_many: bad region table"; return CSV_EINVAL;
+            }
+        if (win_off[c][nr] && (!log2_cov[c] || !win_start[c] || !win_end[c])) { ctx->err = "window_log2_many: null output"; return CSV_EINVAL; }
+        R += nr; W += win_off[c][nr];
+    }
+    if (W == 0) return CSV_OK;
+    (void)hipSetDevice(ctx->device);
+    // one page-locked block carries every shard's tables to the device and every shard's windows back
+    const size_t in_bytes = align_up(R * 4, 8) * 3 + (R + (size_t)n_shards) * 8, out_bytes = W * 8 + 2 * align_up(W * 4, 8);
+    int rc = ensure_pinned(ctx, in_bytes + out_bytes + 4096);
+    if (rc) return rc;
+    if ((rc = arena_reserve(ctx, ctx->arena, in_bytes + out_bytes + 8192))) return rc;
+    char *h_in = (char *)ctx->pinned, *h_out = h_in + align_up(in_bytes, 256);
+    char *d_in = (char *)arena_alloc(ctx->arena, in_bytes), *d_out = (char *)arena_alloc(ctx->arena, out_bytes);
+    if (!d_in || !d_out) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    const size_t o_rs = 0, o_re = align_up(R * 4, 8), o_ss = 2 * align_up(R * 4, 8), o_wo = 3 * align_up(R * 4, 8);
+    const size_t o_l2 = 0, o_ws = W * 8, o_we = W * 8 + align_up(W * 4, 8);
+    uint64_t r0 = 0, w0 = 0;
+    for (int c = 0; c < n_shards; c++) {
+        const uint64_t nr = n_regions[c];
+        if (!nr) continue;
+        memcpy(h_in + o_rs + r0 * 4, region_start[c], nr * 4);
+        memcpy(h_in + o_re + r0 * 4, region_end[c], nr * 4);
+        memcpy(h_in + o_ss + r0 * 4, sample_size[c], nr * 4);
+        memcpy(h_in + o_wo + (r0 + (uint64_t)c) * 8, win_off[c], (nr + 1) * 8);
+        r0 += nr;
+    }
+    hipStream_t s = ctx->stream;
+    CSV_HIP(ctx, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, s));
+    {
+        TimerScope ts(ctx, CSV_K_WINDOW);
+        r0 = 0;
+        for (int c = 0; c < n_shards; c++) {
+            const uint64_t nr = n_regions[c];
+            if (!nr) continue;
+            const uint64_t nw = win_off[c][nr];
+            launch_window_log2(s, shards[c]->depth, shards[c]->depth_len, (const uint32_t *)(d_in + o_rs) + r0, (const uint32_t *)(d_in + o_re) + r0,
+                               (const int32_t *)(d_in + o_ss) + r0, (const uint64_t *)(d_in + o_wo) + r0 + c, nr, nw, mean_cov[c],
+                               (double *)(d_out + o_l2) + w0, (uint32_t *)(d_out + o_ws) + w0, (uint32_t *)(d_out + o_we) + w0);
+            r0 += nr; w0 += nw;
+        }
+    }
+    CSV_HIP(ctx, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipStreamSynchronize(s));
+    w0 = 0;
+    for (int c = 0; c < n_shards; c++) {
+        const uint64_t nr = n_regions[c];
+        if (!nr) continue;
+        const uint64_t nw = win_off[c][nr];
+        memcpy(log2_cov[c], h_out + o_l2 + w0 * 8, nw * 8);
+        memcpy(win_start[c], h_out + o_ws + w0 * 4, nw * 4);
+        memcpy(win_end[c], h_out + o_we + w0 * 4, nw * 4);
+        w0 += nw;
+    }
+    return CSV_OK;
+}
+
 int csvgpu_aln_intervals_gather_batch(csv_ctx *ctx, int n_shards, csv_shard *const *shards, const uint32_t *rec, const uint64_t *rec_off,
                                       int32_t *ref_end, int32_t *q_start, int32_t *q_end)
 {
@@ -895,23 +969,23 @@ int csvgpu_aln_intervals_gather_batch(csv_ctx *ctx, int n_shards, csv_shard *con
     (void)hipSetDevice(ctx->device);
     int rc = arena_reserve(ctx, ctx->arena, 4 * align_up(n * 4, 256) + 4096);
     if (rc) return rc;
+    if ((rc = ensure_pinned(ctx, 4 * align_up(n * 4, 256) + 4096))) return rc;      // the index list goes out and the three arrays come back through one page-locked block
     uint32_t *didx = (uint32_t *)arena_alloc(ctx->arena, n * 4);
-    uint32_t *dout[3];
-    for (int k = 0; k < 3; k++) dout[k] = (uint32_t *)arena_alloc(ctx->arena, n * 4);
-    if (!didx || !dout[0] || !dout[1] || !dout[2]) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    uint32_t *dout = (uint32_t *)arena_alloc(ctx->arena, 3 * n * 4);
+    if (!didx || !dout) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
+    uint32_t *h_idx = (uint32_t *)ctx->pinned, *h_out = h_idx + align_up(n * 4, 256) / 4;
+    memcpy(h_idx, rec, n * 4);
     hipStream_t s = ctx->stream;
-    CSV_HIP(ctx, hipMemcpyAsync(didx, rec, n * 4, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(didx, h_idx, n * 4, hipMemcpyHostToDevice, s));
     for (int c = 0; c < n_shards; c++) {
         const uint64_t o = rec_off[c], m = rec_off[c + 1] - o;
         if (!m) continue;
         const csv_shard *sh = shards[c];
-        launch_gather_u32(s, (const uint32_t *)sh->ref_end, didx + o, m, dout[0] + o);
-        launch_gather_u32(s, (const uint32_t *)sh->q_start, didx + o, m, dout[1] + o);
-        launch_gather_u32(s, (const uint32_t *)sh->q_end, didx + o, m, dout[2] + o);
+        launch_gather3_u32(s, (const uint32_t *)sh->ref_end, (const uint32_t *)sh->q_start, (const uint32_t *)sh->q_end, didx + o, m, dout + o, dout + n + o, dout + 2 * n + o);
     }
-    int32_t *dst[3] = {ref_end, q_start, q_end};
-    for (int k = 0; k < 3; k++) CSV_HIP(ctx, hipMemcpyAsync(dst[k], dout[k], n * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipMemcpyAsync(h_out, dout, 3 * n * 4, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, hipStreamSynchronize(s));
+    memcpy(ref_end, h_out, n * 4); memcpy(q_start, h_out + n, n * 4); memcpy(q_end, h_out + 2 * n, n * 4);
     return CSV_OK;
 }
 
@@ -993,14 +1067,14 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
     uint32_t *blk = (uint32_t *)arena_alloc(ctx->arena, (n_blocks + 1) * 4);
     void *es_tmp = arena_alloc(ctx->arena, exclusive_sum_tmp_bytes(n_blocks + 1));
     uint64_t *node_hash = (uint64_t *)arena_alloc(ctx->arena, total_reads * 8);
-    uint32_t *node_rec = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4), *pos = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4);
+    uint32_t *node_rec = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4), *list = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4);
     uint64_t *d_supp = (uint64_t *)arena_alloc(ctx->arena, n_supp * 8);
-    if (!blk || !es_tmp || !node_hash || !node_rec || !pos || !d_supp) { ctx->err = "arena exhausted (split order)"; return CSV_ENOMEM; }
+    if (!blk || !es_tmp || !node_hash || !node_rec || !list || !d_supp) { ctx->err = "arena exhausted (split order)"; return CSV_ENOMEM; }
     CSV_HIP(ctx, hipMemcpyAsync(d_supp, supp_hash, n_supp * 8, hipMemcpyHostToDevice, s));
     CSV_HIP(ctx, hipMemsetAsync(blk + n_blocks, 0, 4, s));
     launch_so_count(s, tab, (uint32_t)n_blocks, min_mapq, blk);
     launch_exclusive_sum_u32(s, blk, n_blocks + 1, es_tmp);
-    launch_so_scatter(s, tab, (uint32_t)n_blocks, min_mapq, blk, node_hash, node_rec, pos);
+    launch_so_scatter(s, tab, (uint32_t)n_blocks, min_mapq, blk, node_hash, node_rec);
     if ((rc = ensure_pinned(ctx, (n_blocks + 1) * 4 + 64))) return rc;
     CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, blk, (n_blocks + 1) * 4, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, wait_stream(s));
@@ -1036,7 +1110,7 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         for (int c = 0; c < n_contigs; c++) {
             if (N[(size_t)c] <= first_node[k]) continue;
             const uint64_t m = std::min(N[(size_t)c], next_first);                 // nodes present at the end of this epoch
-            e.work_off[e.A] = M; e.nbase[e.A] = tab.nbase[c];
+            e.work_off[e.A] = M; e.nbase[e.A] = tab.nbase[c]; e.m_old[e.A] = (uint32_t)first_node[k];
             e.A++; M += m; m_max = std::max(m_max, m);
         }
         if (e.A == 0) break;
@@ -1044,12 +1118,12 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         if (m_max <= 1) continue;                                                   // a single node: nothing to order
         const uint32_t B = (uint32_t)buckets[k];
         const int wbits = std::max(1, bits_of(m_max - 1));
-        const int key_bits = 2 * wbits + std::max(1, bits_of((uint64_t)e.A - 1));
+        const int key_bits = wbits + std::max(1, bits_of((uint64_t)e.A - 1));
         CSV_HIP(ctx, hipMemsetAsync(minT, 0xff, (size_t)e.A * B * 4, s));
-        launch_so_mint(s, e, M, B, node_hash, pos, minT);
-        launch_so_keys(s, e, M, B, wbits, node_hash, pos, minT, w.k0, w.v0);
+        launch_so_mint(s, e, M, B, node_hash, list, minT);
+        launch_so_keys(s, e, M, B, wbits, node_hash, list, minT, w.k0, w.v0);
         const int io = launch_radix_sort_u64(s, w.k0, w.v0, w.k1, w.v1, M, key_bits, w.tmp);
-        launch_so_setpos(s, e, M, io ? w.v1 : w.v0, pos);
+        launch_so_setlist(s, e, M, io ? w.v1 : w.v0, list);
     }
 
     // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
@@ -1058,7 +1132,7 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
     unsigned long long *d_count = (unsigned long long *)arena_alloc(ctx->work, 256);
     if (!d_out || !d_count) { ctx->err = "arena exhausted (split order survivors)"; return CSV_ENOMEM; }
     CSV_HIP(ctx, hipMemsetAsync(d_count, 0, 8, s));
-    launch_so_survivors(s, tab, n_nodes, node_hash, node_rec, pos, d_supp, n_supp, d_out, cap, d_count);
+    launch_so_survivors(s, tab, n_nodes, node_hash, node_rec, list, d_supp, n_supp, d_out, cap, d_count);
     CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_count, 8, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, wait_stream(s));
     const uint64_t n_surv = *(const unsigned long long *)ctx->pinned;

@@ -232,7 +232,25 @@ void CNVCaller::observeAndDecode(std::vector<RegionBatch> &batches, const std::v
     }
     {
         csvhost::TraceScope tr("cn: window launches");
-        for (size_t j = 0; j < jobs.size(); j++) if (!batches[j].regions.empty()) launchWindows(batches[j], jobs[j].shard, jobs[j].mean_chr_cov);
+        std::vector<csv_shard *> sh;
+        std::vector<const uint32_t *> rs, re;
+        std::vector<const int32_t *> ss;
+        std::vector<const uint64_t *> wo;
+        std::vector<uint64_t> nr;
+        std::vector<double> mean;
+        std::vector<double *> l2;
+        std::vector<uint32_t *> ws, we;
+        for (size_t j = 0; j < jobs.size(); j++) {
+            RegionBatch &B = batches[j];
+            if (B.r_start.empty()) continue;
+            const uint64_t nw = B.win_off.back();
+            B.log2_cov.resize(nw); B.ws.resize(nw); B.we.resize(nw);
+            sh.push_back(jobs[j].shard); rs.push_back(B.r_start.data()); re.push_back(B.r_end.data()); ss.push_back(B.r_ss.data()); wo.push_back(B.win_off.data());
+            nr.push_back(B.r_start.size()); mean.push_back(jobs[j].mean_chr_cov); l2.push_back(B.log2_cov.data()); ws.push_back(B.ws.data()); we.push_back(B.we.data());
+        }
+        if (!sh.empty())
+            check(ctx, csvgpu_window_log2_resident_many(ctx, (int)sh.size(), sh.data(), rs.data(), re.data(), ss.data(), wo.data(), nr.data(), mean.data(), l2.data(),
+                                                        ws.data(), we.data()), "querySNPRegion");
     }
     const size_t n = G.cands.size();
     G.chunks.assign((n + kChunk - 1) / kChunk, ObsChunk());

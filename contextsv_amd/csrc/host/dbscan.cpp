@@ -74,6 +74,13 @@ void DBSCAN1D::fitBatch(const std::vector<std::vector<int>> &sets, double epsilo
     for (size_t k = 0; k < sets.size(); k++) labels[k].assign(lab.begin() + off[k], lab.begin() + off[k + 1]);
 }
 
+void DBSCAN1D::fitBatchFlat(const std::vector<int> &points, const std::vector<uint64_t> &off, double epsilon, int minPts, std::vector<int> &labels)
+{
+    labels.assign(points.size(), -1);
+    if (points.empty() || off.size() < 2) return;
+    check(csvgpu_dbscan_1d(csvhost::context(), points.data(), off.data(), off.size() - 1, epsilon, minPts, labels.data()), "DBSCAN1D::fitBatch");
+}
+
 // members of the most populated cluster in index order; the first strictly larger bucket in ascending
 // id order wins, so ties go to the lowest id; no cluster -> empty (reference dbscan1d.cpp:72-90)
 std::vector<int> DBSCAN1D::getLargestCluster(const std::vector<int> &points)

@@ -36,6 +36,8 @@ public:
 
     // batched form: one device call for many point sets (the six fits per overlap group of the split-read path)
     static void fitBatch(const std::vector<std::vector<int>> &sets, double epsilon, int minPts, std::vector<std::vector<int>> &labels);
+    // the same on flat arrays: set k = points[off[k] .. off[k+1]), labels in the same layout
+    static void fitBatchFlat(const std::vector<int> &points, const std::vector<uint64_t> &off, double epsilon, int minPts, std::vector<int> &labels);
 
 private:
     double epsilon;

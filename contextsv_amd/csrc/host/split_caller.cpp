@@ -76,18 +76,19 @@ struct IntervalTree {
     }
 };
 
-// DBSCAN1D::getLargestCluster on precomputed labels (dbscan1d.cpp:72-90)
-std::vector<int> largest_cluster(const std::vector<int> &points, const std::vector<int> &labels)
+// DBSCAN1D::getLargestCluster on precomputed labels (dbscan1d.cpp:72-90); labels[i] belongs to points[i]
+std::vector<int> largest_cluster(const std::vector<int> &points, const int *labels)
 {
+    const size_t n = points.size();
     int max_id = -1;
-    for (int c : labels) max_id = std::max(max_id, c);
+    for (size_t i = 0; i < n; i++) max_id = std::max(max_id, labels[i]);
     std::vector<size_t> sizes((size_t)(max_id + 1), 0);
-    for (int c : labels) if (c >= 0) sizes[(size_t)c]++;
+    for (size_t i = 0; i < n; i++) if (labels[i] >= 0) sizes[(size_t)labels[i]]++;
     int best = -1; size_t best_n = 0;
     for (int c = 0; c <= max_id; c++) if (sizes[(size_t)c] > best_n) { best_n = sizes[(size_t)c]; best = c; }
     std::vector<int> out;
     if (best < 0) return out;
-    for (size_t i = 0; i < labels.size(); i++) if (labels[i] == best) out.push_back(points[i]);
+    for (size_t i = 0; i < n; i++) if (labels[i] == best) out.push_back(points[i]);
     return out;
 }
 
@@ -178,13 +179,26 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
             W.last_rec.push_back((uint32_t)i);
         }
         if (!dev) W.n_primary = W.first_rec.size();
+        std::sort(W.supps.begin(), W.supps.end(), [](const SuppRef &a, const SuppRef &b) { return a.hash != b.hash ? a.hash < b.hash : a.ord < b.ord; });
     });
 
     // ---- supp_map: every supplementary record of the run by name, file order within a name (:162-165) ---------------------------
     tr.reset(new csvhost::TraceScope("split: supp index"));
     std::vector<SuppRef> supp_index;
-    for (const ContigWork &W : work) supp_index.insert(supp_index.end(), W.supps.begin(), W.supps.end());
-    std::sort(supp_index.begin(), supp_index.end(), [](const SuppRef &a, const SuppRef &b) { return a.hash != b.hash ? a.hash < b.hash : a.ord < b.ord; });
+    {   // the contigs' lists are sorted (phase 1): merge them pairwise
+        auto less = [](const SuppRef &a, const SuppRef &b) { return a.hash != b.hash ? a.hash < b.hash : a.ord < b.ord; };
+        std::vector<size_t> cut{0};
+        for (const ContigWork &W : work) { supp_index.insert(supp_index.end(), W.supps.begin(), W.supps.end()); cut.push_back(supp_index.size()); }
+        while (cut.size() > 2) {
+            std::vector<size_t> next{0};
+            for (size_t k = 0; k + 2 < cut.size(); k += 2) {
+                std::inplace_merge(supp_index.begin() + (std::ptrdiff_t)cut[k], supp_index.begin() + (std::ptrdiff_t)cut[k + 1], supp_index.begin() + (std::ptrdiff_t)cut[k + 2], less);
+                next.push_back(cut[k + 2]);
+            }
+            if (cut.size() % 2 == 0) next.push_back(cut.back());
+            cut.swap(next);
+        }
+    }
 
     // ---- the device's share: which primaries have a supplementary record's name hash, in the map's iteration order ----------------
     tr.reset(new csvhost::TraceScope("split: device order"));
@@ -329,12 +343,14 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
 
     // ---- the six DBSCAN1D(100, 5) fits of every group of every contig: ONE batched launch (:270-372) ------------------------------
     tr.reset(new csvhost::TraceScope("split: dbscan1d batch"));
-    std::vector<std::vector<int>> flat_sets, flat_labels;
+    std::vector<int> flat_pts, flat_labels;
+    std::vector<uint64_t> flat_off{0};
     for (ContigWork &W : work) {
-        W.set_base = flat_sets.size();
-        for (Group &G : W.groups) for (int s = 0; s < 6; s++) flat_sets.push_back(G.sets[s]);
+        W.set_base = flat_off.size() - 1;
+        for (Group &G : W.groups)
+            for (int s = 0; s < 6; s++) { flat_pts.insert(flat_pts.end(), G.sets[s].begin(), G.sets[s].end()); flat_off.push_back(flat_pts.size()); }
     }
-    if (!flat_sets.empty()) DBSCAN1D::fitBatch(flat_sets, params.eps, params.min_pts, flat_labels);
+    if (!flat_pts.empty()) DBSCAN1D::fitBatchFlat(flat_pts, flat_off, params.eps, params.min_pts, flat_labels);
 
     // ---- phase 3: medians, SPLITDIST1 candidates, SPLIT dummies (:283-486), per contig --------------------------------------------
     tr.reset(new csvhost::TraceScope("split: calls"));
@@ -346,7 +362,7 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
         for (size_t g = 0; g < W.groups.size(); g++) {
             Group &G = W.groups[g];
             std::vector<int> cl[6];
-            for (int s = 0; s < 6; s++) cl[s] = largest_cluster(G.sets[s], flat_labels[W.set_base + g * 6 + (size_t)s]);
+            for (int s = 0; s < 6; s++) cl[s] = largest_cluster(G.sets[s], flat_labels.data() + flat_off[W.set_base + g * 6 + (size_t)s]);
             std::vector<int> &p_start = cl[0], &p_end = cl[1], &s_start = cl[2], &s_end = cl[3], &read_d = cl[4], &ref_d = cl[5];
             if (p_start.empty() && p_end.empty()) continue;                                          // :291-293
             if (s_start.empty() && s_end.empty() && read_d.empty() && ref_d.empty()) continue;        // :375-377

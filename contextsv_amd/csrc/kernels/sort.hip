@@ -424,4 +424,19 @@ void launch_check_sorted_u32(hipStream_t s, const uint32_t *k, uint64_t n, unsig
 void launch_gather_u32(hipStream_t s, const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst)
 { if (n) hipLaunchKernelGGL(gather_u32_kernel, GRID1D(n), 0, s, src, idx, n, dst); }
 
+// dst_k[i] = src_k[idx[i]] for three arrays that share the index list (the split-read pass's ref_end / q_start / q_end of selected records)
+__global__ __launch_bounds__(256) void gather3_u32_kernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, const uint32_t *__restrict__ c,
+                                                          const uint32_t *__restrict__ idx, uint64_t n, uint32_t *__restrict__ da, uint32_t *__restrict__ db,
+                                                          uint32_t *__restrict__ dc)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = idx[i];
+    da[i] = a[k]; db[i] = b[k]; dc[i] = c[k];
+}
+void launch_gather3_u32(hipStream_t s, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *idx, uint64_t n, uint32_t *da, uint32_t *db, uint32_t *dc)
+{
+    if (n) hipLaunchKernelGGL(gather3_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, c, idx, n, da, db, dc);
+}
+
 }  // namespace csv

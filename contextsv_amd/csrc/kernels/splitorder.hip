@@ -9,8 +9,8 @@
 // then the list at the end of the epoch is the nodes sorted by (min t of the node's bucket, descending; t, descending).
 // So the order of N keys is a chain of ~log2(N) stable sorts of geometrically growing size (~2N keys sorted in all), each of them:
 //   so_mint   minT[bucket] = min t            (atomicMin; bucket = hash % B, B from the library's own _Prime_rehash_policy)
-//   so_keys   key = contig | ~minT | ~t       (all contigs of the genome share every launch)
-//   radix sort (sort.hip), so_setpos           position of every node in the new list
+//   so_keys   key = contig | ~minT, items enumerated in descending t (all contigs of the genome share every launch)
+//   stable radix sort (sort.hip), so_setlist    the new list
 // and the survivors (nodes whose name hash is among the supplementary records' hashes) leave with their final position.
 // Checked against umap_order.h (which is checked against the real container) in tests/test_gpu_split_order.py.
 #include "../common.hpp"
@@ -55,12 +55,11 @@ __global__ __launch_bounds__(SO_THREADS) void so_count_kernel(SplitOrderTab tab,
 
 // blk_off = exclusive sum of blk_cnt over ALL blocks: a contig's first block holds its first node's global index
 __global__ __launch_bounds__(SO_THREADS) void so_scatter_kernel(SplitOrderTab tab, uint32_t min_mapq, const uint32_t *__restrict__ blk_off,
-                                                                uint64_t *__restrict__ node_hash, uint32_t *__restrict__ node_rec, uint32_t *__restrict__ pos)
+                                                                uint64_t *__restrict__ node_hash, uint32_t *__restrict__ node_rec)
 {
     const uint32_t a = so_owner(tab, blockIdx.x, tab.blk_off);
     const uint64_t r0 = (uint64_t)(blockIdx.x - tab.blk_off[a]) * SO_BLOCK;
     const uint64_t n = tab.n_reads[a];
-    const uint32_t contig_base = blk_off[tab.blk_off[a]];
     __shared__ uint32_t ws[SO_THREADS / WAVE];
     uint32_t base = blk_off[blockIdx.x];
     for (int k0 = 0; k0 < SO_BLOCK; k0 += SO_THREADS) {
@@ -76,7 +75,6 @@ __global__ __launch_bounds__(SO_THREADS) void so_scatter_kernel(SplitOrderTab ta
             const uint32_t g = base + wbase + before;
             node_hash[g] = tab.qhash[a][r];
             node_rec[g] = (uint32_t)r;
-            pos[g] = g - contig_base;                      // not yet in any list: its processing time is its insertion index
         }
         base += tot;
         __syncthreads();
@@ -84,57 +82,74 @@ __global__ __launch_bounds__(SO_THREADS) void so_scatter_kernel(SplitOrderTab ta
 }
 
 // ---- one epoch ------------------------------------------------------------------------------------------------------------------------
-// work item j of active contig a (tab.work_off) = node nbase[a] + (j - work_off[a]), i.e. the nodes inserted so far
+// Work item j of active contig a enumerates the contig's present nodes in DESCENDING processing time t: the nodes that were in the list
+// when the epoch began sit at t = their list position (list[]), the ones inserted during the epoch at t = their insertion index (which is
+// also their node index). A STABLE sort of the items by (contig, bucket time descending) then leaves every bucket's nodes in descending
+// own time without t being part of the key: four 8-bit passes instead of six.
+__device__ __forceinline__ uint32_t so_node_at(const SplitOrderTab &tab, uint32_t a, uint32_t t, const uint32_t *__restrict__ list)
+{
+    return tab.nbase[a] + (t < tab.m_old[a] ? list[tab.nbase[a] + t] : t);
+}
+
 __global__ __launch_bounds__(SO_THREADS) void so_mint_kernel(SplitOrderTab tab, uint64_t M, uint32_t B, const uint64_t *__restrict__ node_hash,
-                                                             const uint32_t *__restrict__ pos, uint32_t *__restrict__ minT)
+                                                             const uint32_t *__restrict__ list, uint32_t *__restrict__ minT)
 {
     const uint64_t j = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
     if (j >= M) return;
     const uint32_t a = so_owner(tab, j, tab.work_off);
-    const uint32_t g = tab.nbase[a] + (uint32_t)(j - tab.work_off[a]);
+    const uint32_t m = (uint32_t)(tab.work_off[a + 1] - tab.work_off[a]);
+    const uint32_t t = m - 1u - (uint32_t)(j - tab.work_off[a]);
+    const uint32_t g = so_node_at(tab, a, t, list);
     const uint32_t b = (uint32_t)(node_hash[g] % (uint64_t)B);
-    atomicMin(&minT[(uint64_t)a * B + b], pos[g]);
+    atomicMin(&minT[(uint64_t)a * B + b], t);
 }
 
 __global__ __launch_bounds__(SO_THREADS) void so_keys_kernel(SplitOrderTab tab, uint64_t M, uint32_t B, int w, const uint64_t *__restrict__ node_hash,
-                                                             const uint32_t *__restrict__ pos, const uint32_t *__restrict__ minT,
+                                                             const uint32_t *__restrict__ list, const uint32_t *__restrict__ minT,
                                                              uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const uint64_t j = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
     if (j >= M) return;
     const uint32_t a = so_owner(tab, j, tab.work_off);
-    const uint32_t g = tab.nbase[a] + (uint32_t)(j - tab.work_off[a]);
+    const uint32_t m = (uint32_t)(tab.work_off[a + 1] - tab.work_off[a]);
+    const uint32_t t = m - 1u - (uint32_t)(j - tab.work_off[a]);
+    const uint32_t g = so_node_at(tab, a, t, list);
     const uint32_t b = (uint32_t)(node_hash[g] % (uint64_t)B);
     const uint64_t mask = (1ull << w) - 1ull;
-    // ascending sort: contig, then LARGER bucket time first, then LARGER own time first
-    keys[j] = ((uint64_t)a << (2 * w)) | ((mask - (uint64_t)minT[(uint64_t)a * B + b]) << w) | (mask - (uint64_t)pos[g]);
-    vals[j] = g;
+    keys[j] = ((uint64_t)a << w) | (mask - (uint64_t)minT[(uint64_t)a * B + b]);      // ascending: contig, then LARGER bucket time first
+    vals[j] = g - tab.nbase[a];                                                        // node index inside its contig
 }
 
-__global__ __launch_bounds__(SO_THREADS) void so_setpos_kernel(SplitOrderTab tab, uint64_t M, const uint32_t *__restrict__ vals, uint32_t *__restrict__ pos)
+// the sorted items are the new lists, contig after contig
+__global__ __launch_bounds__(SO_THREADS) void so_setlist_kernel(SplitOrderTab tab, uint64_t M, const uint32_t *__restrict__ vals, uint32_t *__restrict__ list)
 {
     const uint64_t j = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
     if (j >= M) return;
     const uint32_t a = so_owner(tab, j, tab.work_off);
-    pos[vals[j]] = (uint32_t)(j - tab.work_off[a]);
+    list[tab.nbase[a] + (uint32_t)(j - tab.work_off[a])] = vals[j];
 }
 
 // ---- the nodes that survive the erase: their name hash is among the supplementary records' (sorted, distinct) hashes ----------------
+// item = (contig a, list position p): node list[p] of the contig's final list (a contig with a single node never went through an epoch:
+// its list is the node itself)
 __global__ __launch_bounds__(SO_THREADS) void so_survivors_kernel(SplitOrderTab tab, uint64_t n_nodes, const uint64_t *__restrict__ node_hash,
-                                                                  const uint32_t *__restrict__ node_rec, const uint32_t *__restrict__ pos,
+                                                                  const uint32_t *__restrict__ node_rec, const uint32_t *__restrict__ list,
                                                                   const uint64_t *__restrict__ supp_hash, uint64_t n_supp, csv_split_survivor *__restrict__ out,
                                                                   uint64_t cap, unsigned long long *__restrict__ count)
 {
-    const uint64_t g = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
-    if (g >= n_nodes) return;
+    const uint64_t x = (uint64_t)blockIdx.x * SO_THREADS + threadIdx.x;
+    if (x >= n_nodes) return;
+    uint32_t a = 0;
+    for (uint32_t k = 1; k < tab.A; k++) a += (x >= tab.nbase[k]);
+    const uint32_t p = (uint32_t)x - tab.nbase[a];
+    const uint32_t n_a = tab.nbase[a + 1] - tab.nbase[a];
+    const uint32_t g = tab.nbase[a] + (n_a > 1 ? list[x] : 0u);
     const uint64_t h = node_hash[g];
     uint64_t lo = 0, hi = n_supp;
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (supp_hash[mid] < h) lo = mid + 1; else hi = mid; }
     if (lo >= n_supp || supp_hash[lo] != h) return;
-    uint32_t a = 0;
-    for (uint32_t k = 1; k < tab.A; k++) a += (g >= tab.nbase[k]);
     const unsigned long long slot = atomicAdd(count, 1ull);
-    if (slot < cap) out[slot] = csv_split_survivor{a, pos[g], node_rec[g]};
+    if (slot < cap) out[slot] = csv_split_survivor{a, p, node_rec[g]};
 }
 
 void launch_so_count(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, uint32_t *blk_cnt)
@@ -142,28 +157,28 @@ void launch_so_count(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks,
     if (n_blocks) hipLaunchKernelGGL(so_count_kernel, dim3(n_blocks), dim3(SO_THREADS), 0, s, tab, min_mapq, blk_cnt);
 }
 void launch_so_scatter(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, const uint32_t *blk_off, uint64_t *node_hash,
-                       uint32_t *node_rec, uint32_t *pos)
+                       uint32_t *node_rec)
 {
-    if (n_blocks) hipLaunchKernelGGL(so_scatter_kernel, dim3(n_blocks), dim3(SO_THREADS), 0, s, tab, min_mapq, blk_off, node_hash, node_rec, pos);
+    if (n_blocks) hipLaunchKernelGGL(so_scatter_kernel, dim3(n_blocks), dim3(SO_THREADS), 0, s, tab, min_mapq, blk_off, node_hash, node_rec);
 }
 static inline unsigned so_grid(uint64_t n) { return (unsigned)((n + SO_THREADS - 1) / SO_THREADS); }
-void launch_so_mint(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, const uint64_t *node_hash, const uint32_t *pos, uint32_t *minT)
+void launch_so_mint(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, const uint64_t *node_hash, const uint32_t *list, uint32_t *minT)
 {
-    if (M) hipLaunchKernelGGL(so_mint_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, B, node_hash, pos, minT);
+    if (M) hipLaunchKernelGGL(so_mint_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, B, node_hash, list, minT);
 }
-void launch_so_keys(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, int w, const uint64_t *node_hash, const uint32_t *pos,
+void launch_so_keys(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_t B, int w, const uint64_t *node_hash, const uint32_t *list,
                     const uint32_t *minT, uint64_t *keys, uint32_t *vals)
 {
-    if (M) hipLaunchKernelGGL(so_keys_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, B, w, node_hash, pos, minT, keys, vals);
+    if (M) hipLaunchKernelGGL(so_keys_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, B, w, node_hash, list, minT, keys, vals);
 }
-void launch_so_setpos(hipStream_t s, const SplitOrderTab &tab, uint64_t M, const uint32_t *vals, uint32_t *pos)
+void launch_so_setlist(hipStream_t s, const SplitOrderTab &tab, uint64_t M, const uint32_t *vals, uint32_t *list)
 {
-    if (M) hipLaunchKernelGGL(so_setpos_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, vals, pos);
+    if (M) hipLaunchKernelGGL(so_setlist_kernel, dim3(so_grid(M)), dim3(SO_THREADS), 0, s, tab, M, vals, list);
 }
-void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nodes, const uint64_t *node_hash, const uint32_t *node_rec, const uint32_t *pos,
+void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nodes, const uint64_t *node_hash, const uint32_t *node_rec, const uint32_t *list,
                          const uint64_t *supp_hash, uint64_t n_supp, csv_split_survivor *out, uint64_t cap, unsigned long long *count)
 {
-    if (n_nodes) hipLaunchKernelGGL(so_survivors_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, tab, n_nodes, node_hash, node_rec, pos, supp_hash, n_supp, out, cap, count);
+    if (n_nodes) hipLaunchKernelGGL(so_survivors_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, tab, n_nodes, node_hash, node_rec, list, supp_hash, n_supp, out, cap, count);
 }
 
 }  // namespace csv

@@ -316,6 +316,14 @@ int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *
                                 const int32_t *sample_size, const uint64_t *win_off, uint64_t n_regions, double mean_cov,
                                 double *log2_cov, uint32_t *win_start, uint32_t *win_end);
 
+/* csvgpu_window_log2_resident for several shards in one call (the copy-number pass of a whole run: one region table per contig, each
+ * evaluated on its own resident depth map; cnv_caller.cpp:76-113): table c has n_regions[c] regions, its win_off[c] starts at 0, its
+ * outputs go to log2_cov[c] / win_start[c] / win_end[c]. One transfer in, one launch per shard, one transfer out, one wait. */
+int csvgpu_window_log2_resident_many(csv_ctx *ctx, int n_shards, csv_shard *const *shards, const uint32_t *const *region_start,
+                                     const uint32_t *const *region_end, const int32_t *const *sample_size, const uint64_t *const *win_off,
+                                     const uint64_t *n_regions, const double *mean_cov, double *const *log2_cov, uint32_t *const *win_start,
+                                     uint32_t *const *win_end);
+
 /* depth_out[i] = depth[pos[i]] on the depth map resident in `shard`, or -1 where pos[i] >= depth_len: the VCF writer's
  * SUPPORT / DP lookups (SVCaller::getReadDepth, sv_caller.cpp:1332-1344, called at :1306) without moving the map. */
 int csvgpu_depth_lookup_resident(csv_ctx *ctx, csv_shard *shard, const uint32_t *pos, uint64_t n, int32_t *depth_out);
