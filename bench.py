@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only (no chr22 / chr1 / from-file legs)")
     ap.add_argument("--no-from-file", action="store_true")
-    ap.add_argument("--cpu-sample-frac", type=float, default=0.15, help="leading fraction of every contig's reads given to the CPU baseline")
+    ap.add_argument("--cpu-sample-frac", type=float, default=0.25, help="leading fraction of every contig's reads given to the CPU baseline")
     ap.add_argument("--verify-against-single", action="store_true", help="rank 0 also stages the WHOLE genome, runs it alone and asserts that the gathered "
                     "call set of the sharded run is byte-identical (rehearsals / tests; costs rank 0 the whole staging)")
     ap.add_argument("--dump-calls", default="", help="rank 0: write the gathered merged calls (npy: tid + CALL_DTYPE) here")

@@ -242,14 +242,17 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
         std::vector<size_t> which;
         std::vector<uint32_t> rec;
         std::vector<uint64_t> rec_off{0};
-        for (size_t c = 0; c < work.size(); c++) {
+        parallel_over(work.size(), params.threads, [&](size_t c) {
             ContigWork &W = work[c];
-            if (W.in->ref_end) continue;
+            if (W.in->ref_end) return;
             for (uint32_t r : W.member_rec) W.need.push_back(r);
             for (const SuppRef &sr : W.supps) W.need.push_back(sr.rec);
             std::sort(W.need.begin(), W.need.end());
             W.need.erase(std::unique(W.need.begin(), W.need.end()), W.need.end());
-            if (W.need.empty()) continue;
+        });
+        for (size_t c = 0; c < work.size(); c++) {
+            ContigWork &W = work[c];
+            if (W.in->ref_end || W.need.empty()) continue;
             which.push_back(c);
             rec.insert(rec.end(), W.need.begin(), W.need.end());
             rec_off.push_back(rec.size());

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(ES_THREADS) void es_down_kernel(uint32_t *__restric
 constexpr int ES1_THREADS = 1024;
 constexpr int ES1_PER = 16;                        // entries per thread per chunk
 constexpr int ES1_CHUNK = ES1_THREADS * ES1_PER;   // 16384 entries (64 KiB of LDS) per chunk
-constexpr uint64_t ES1_MAX = 1ull << 21;
+constexpr uint64_t ES1_MAX = 1ull << 16;      // beyond four chunks the three-launch form wins (one workgroup takes ~0.1 us per Ki entries: 215 us for the 1.2 M-entry table of a 5 M-key radix pass)
 __global__ __launch_bounds__(ES1_THREADS) void es_single_kernel(uint32_t *__restrict__ data, uint64_t n)
 {
     __shared__ uint32_t buf[ES1_CHUNK + ES1_CHUNK / 32];   // +1 word of padding every 32: the per-thread runs stay conflict-light
