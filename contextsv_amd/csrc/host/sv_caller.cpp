@@ -14,6 +14,7 @@
 
 #include "dbscan.h"
 #include "log.h"
+#include "par.h"
 #include "sort_select.h"
 #include "umap_order.h"
 
@@ -199,9 +200,10 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
     std::vector<char> ready(n, 0), merged(n, 0);          // guarded by mu
     bool failed = false;
     std::exception_ptr worker_err;
-    std::vector<std::thread> workers;
+    csvhost::WorkerThreads &pool = csvhost::WorkerThreads::instance();
+    std::vector<csvhost::WorkerThreads::Ticket> workers;
     for (size_t w = 0; w < kMergers; w++) {
-        workers.emplace_back([&, w] {
+        workers.push_back(pool.start([&, w] {
             try {
                 for (size_t i = w; i < n; i += kMergers) {
                     { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return ready[i] || failed; }); if (failed) return; }
@@ -215,12 +217,12 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
                 failed = true;
                 cv.notify_all();
             }
-        });
+        }));
     }
     auto stop_workers = [&] {
         { std::lock_guard<std::mutex> l(mu); failed = true; }
         cv.notify_all();
-        for (auto &t : workers) t.join();
+        for (auto &t : workers) pool.wait(t);
     };
     csv_job *ahead = nullptr;                             // the job whose scan + depth pass is already queued
     try {
@@ -274,7 +276,7 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
         stop_workers();
         throw;
     }
-    for (auto &t : workers) t.join();
+    for (auto &t : workers) pool.wait(t);
     if (worker_err) std::rethrow_exception(worker_err);
 }
 
@@ -284,17 +286,18 @@ void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqSto
     calls.assign(lanes.size(), {});
     stats.assign(lanes.size(), {});
     std::vector<std::exception_ptr> errs(lanes.size());
-    std::vector<std::thread> threads;
+    csvhost::WorkerThreads &pool = csvhost::WorkerThreads::instance();
+    std::vector<csvhost::WorkerThreads::Ticket> threads;
     for (size_t l = 0; l < lanes.size(); l++) {
-        threads.emplace_back([&, l] {
+        threads.push_back(pool.start([&, l] {
             try {
                 SVCaller caller(lanes[l].ctx);
                 if (!lanes[l].seqs.empty()) caller.processResidentChromosomesPipelined(lanes[l].shards, lanes[l].seqs, eps, pct, calls[l], stats[l]);
                 else caller.processResidentChromosomesPipelined(lanes[l].shards, seq, eps, pct, calls[l], stats[l]);
             } catch (...) { errs[l] = std::current_exception(); }
-        });
+        }));
     }
-    for (auto &t : threads) t.join();
+    for (auto &t : threads) pool.wait(t);
     for (auto &e : errs) if (e) std::rethrow_exception(e);
 }
 

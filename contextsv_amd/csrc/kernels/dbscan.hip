@@ -444,6 +444,14 @@ void launch_dbscan_1d_big(hipStream_t s, const int32_t *pts_sorted, const uint32
 // One workgroup per set, everything in LDS, brute force over all pairs with the reference's predicate: core flags, union-find of the
 // core points (larger root under smaller: a component's root is its smallest original index = its start point), start points ranked
 // in index order, then the border rule. Same order-free labelling as the windowed kernels above; no sort, no scratch in HBM.
+// Intervals that share no position are never neighbours for eps < 1 (overlap 0 -> distance 1, or NaN for an empty interval): in a set
+// that spans a contig that is almost every pair, and a wave whose 64 points all miss interval j skips the division path altogether.
+__device__ __forceinline__ bool ivs_nb(uint32_t s1, uint32_t e1, uint32_t s2, uint32_t e2, double eps)
+{
+    if (min((int)e1, (int)e2) <= max((int)s1, (int)s2)) return false;
+    return iv_neighbor(s1, e1, s2, e2, eps);
+}
+
 constexpr int IVS_THREADS = 256;
 constexpr int IVS_MAX = (int)DBSCAN_IV_SMALL_MAX;
 
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(IVS_THREADS) void dbscan_iv_small_kernel(const uint
         for (int i = threadIdx.x; i < n; i += IVS_THREADS) {
             const uint32_t si = ls[i], ei = le[i];
             int cnt = 0;
-            for (int j = 0; j < n; j++) cnt += iv_neighbor(si, ei, ls[j], le[j], eps);
+            for (int j = 0; j < n; j++) cnt += ivs_nb(si, ei, ls[j], le[j], eps);
             lcore[i] = cnt >= min_pts;
         }
         __syncthreads();
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(IVS_THREADS) void dbscan_iv_small_kernel(const uint
             if (!lcore[i]) continue;
             const uint32_t si = ls[i], ei = le[i];
             for (int j = i + 1; j < n; j++) {
-                if (!lcore[j] || !iv_neighbor(si, ei, ls[j], le[j], eps)) continue;
+                if (!lcore[j] || !ivs_nb(si, ei, ls[j], le[j], eps)) continue;
                 uint32_t a = (uint32_t)i, b = (uint32_t)j;
                 for (;;) {
                     a = lds_find(lpar, a); b = lds_find(lpar, b);
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(IVS_THREADS) void dbscan_iv_small_kernel(const uint
                 const uint32_t si = ls[i], ei = le[i];
                 int32_t max_start = -1, min_core = INT32_MAX;
                 for (int j = 0; j < n; j++) {
-                    if (!lcore[j] || !iv_neighbor(si, ei, ls[j], le[j], eps)) continue;
+                    if (!lcore[j] || !ivs_nb(si, ei, ls[j], le[j], eps)) continue;
                     const uint32_t rj = lds_find(lpar, (uint32_t)j);
                     const int32_t c = (int32_t)lcid[rj];
                     if (rj == (uint32_t)j) max_start = max(max_start, c); else min_core = min(min_core, c);
