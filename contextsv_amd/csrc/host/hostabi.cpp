@@ -571,7 +571,7 @@ int csvhost_genome_add_synth(csvhost_genome *g, csv_ctx *ctx, const char *name, 
 }
 
 struct csvhost_stage_times {
-    double ms_cigar, ms_cigar_cn, ms_split_fetch, ms_split, ms_split_cn, ms_merge_split, ms_merge_final, ms_vcf, ms_total;
+    double ms_cigar, ms_cigar_cn, ms_split_fetch, ms_split, ms_split_cn, ms_merge_split, ms_merge_final, ms_vcf, ms_total, ms_split_prepare;
     uint64_t n_reads, n_signatures, n_cigar_calls, n_cigar_cn_regions, n_split_calls, n_final_calls;
 };
 
@@ -633,7 +633,7 @@ int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *co
         if (times) {
             times->ms_cigar = T.ms_cigar; times->ms_cigar_cn = T.ms_cigar_cn; times->ms_split_fetch = T.ms_split_fetch; times->ms_split = T.ms_split;
             times->ms_split_cn = T.ms_split_cn; times->ms_merge_split = T.ms_merge_split; times->ms_merge_final = T.ms_merge_final; times->ms_vcf = T.ms_vcf;
-            times->ms_total = T.ms_total; times->n_reads = T.n_reads; times->n_signatures = T.n_signatures; times->n_cigar_calls = T.n_cigar_calls;
+            times->ms_total = T.ms_total; times->ms_split_prepare = T.ms_split_prepare; times->n_reads = T.n_reads; times->n_signatures = T.n_signatures; times->n_cigar_calls = T.n_cigar_calls;
             times->n_cigar_cn_regions = T.n_cigar_cn_regions; times->n_split_calls = T.n_split_calls; times->n_final_calls = T.n_final_calls;
         }
     })

@@ -139,18 +139,47 @@ void parallel_over(size_t n, int threads, F f) { csvhost::parallel_for(n, thread
 
 }  // namespace
 
+// findSplitSVSignatures in two halves, so that a run can do the first — everything that needs no alignment intervals: the primaries and
+// supplementaries, the qname map's iteration order, the survivors (sv_caller.cpp:137-202) — while the device is still busy with the
+// CIGAR pass, and the second — intervals, tree, groups, fits, calls (:205-498) — once the scan's per-read outputs exist.
+struct SplitPass::Impl {
+    const std::vector<SplitContig> &contigs;
+    const std::vector<std::string> &target_names;
+    SplitParams params;
+    std::vector<size_t> by_size;
+    std::vector<ContigWork> work;
+    std::vector<SuppRef> supp_index;
+    std::vector<std::vector<uint32_t>> dev_recs;
+    Impl(const std::vector<SplitContig> &c, const std::vector<std::string> &t, const SplitParams &p) : contigs(c), target_names(t), params(p) {}
+    void prepare();
+    void finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
+};
+
+SplitPass::SplitPass(const std::vector<SplitContig> &contigs, const std::vector<std::string> &target_names, const SplitParams &params)
+    : p(new Impl(contigs, target_names, params)) {}
+SplitPass::~SplitPass() = default;
+void SplitPass::prepare() { p->prepare(); prepared = true; }
+void SplitPass::finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls) { if (!prepared) prepare(); p->finish(sv_calls); }
+
 void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::vector<std::string> &target_names, const SplitParams &params,
                            std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
+{
+    SplitPass pass(contigs, target_names, params);
+    pass.prepare();
+    pass.finish(sv_calls);
+}
+
+void SplitPass::Impl::prepare()
 {
     for (const SplitContig &c : contigs)
         if (c.n && (!c.qhash || (!c.name_id && !(c.name_bytes && c.name_off)) || (!params.intervals && !(c.ref_end && c.q_start && c.q_end))))
             throw std::runtime_error("findSplitSVSignatures: a contig without query-name hashes / identities or without alignment intervals");
     // larger contigs first: the wall time of a parallel phase is the largest contig's
-    std::vector<size_t> by_size(contigs.size());
+    by_size.assign(contigs.size(), 0);
     for (size_t i = 0; i < by_size.size(); i++) by_size[i] = i;
     std::sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return contigs[a].n != contigs[b].n ? contigs[a].n > contigs[b].n : a < b; });
     // one work item per tid (a tid split over several blocks is one map in the reference: blocks of a tid are chained in order)
-    std::vector<ContigWork> work(contigs.size());
+    work = std::vector<ContigWork>(contigs.size());
     for (size_t c = 0; c < contigs.size(); c++) {
         work[c].in = &contigs[c];
         for (size_t d = 0; d < c; d++) if (contigs[d].tid == contigs[c].tid) throw std::runtime_error("findSplitSVSignatures: two blocks with the same tid");
@@ -184,7 +213,6 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
 
     // ---- supp_map: every supplementary record of the run by name, file order within a name (:162-165) ---------------------------
     tr.reset(new csvhost::TraceScope("split: supp index"));
-    std::vector<SuppRef> supp_index;
     {   // the contigs' lists are sorted (phase 1): merge them pairwise
         auto less = [](const SuppRef &a, const SuppRef &b) { return a.hash != b.hash ? a.hash < b.hash : a.ord < b.ord; };
         std::vector<size_t> cut{0};
@@ -203,7 +231,6 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
     // ---- the device's share: which primaries have a supplementary record's name hash, in the map's iteration order ----------------
     tr.reset(new csvhost::TraceScope("split: device order"));
     std::vector<size_t> dev_contigs;
-    std::vector<std::vector<uint32_t>> dev_recs;
     for (size_t c = 0; c < contigs.size(); c++) if (on_device(c) && work[c].n_primary) dev_contigs.push_back(c);
     if (!dev_contigs.empty()) {
         std::vector<uint64_t> supp_hash;
@@ -235,6 +262,13 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
         W.order = csvhost::UMapOrder(); W.first_rec = {}; W.last_rec = {};             // the map's storage is not needed any more
     });
 
+    printMessage("Removed " + std::to_string(total_removed.load()) + " primary alignments without supplementary alignments");
+    tr.reset();
+}
+
+void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
+{
+    std::unique_ptr<csvhost::TraceScope> tr;
     // ---- the alignment intervals of the records that are left (ref_end / q_start / q_end of the scan kernel): straight from the
     // arrays, or — contigs that carry an IntervalSource — gathered for just these records (a few per cent of the contig's) ----------
     tr.reset(new csvhost::TraceScope("split: interval gather"));
@@ -342,7 +376,6 @@ void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::v
             }
         }
     });
-    printMessage("Removed " + std::to_string(total_removed.load()) + " primary alignments without supplementary alignments");
 
     // ---- the six DBSCAN1D(100, 5) fits of every group of every contig: ONE batched launch (:270-372) ------------------------------
     tr.reset(new csvhost::TraceScope("split: dbscan1d batch"));

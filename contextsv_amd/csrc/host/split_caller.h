@@ -10,6 +10,7 @@
 // overlap groups, medians and votes — one host thread per contig, contigs being independent.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -81,6 +82,20 @@ struct SplitContig {
 // file order (or carry file_idx): a read's supplementary records are visited in file order.
 void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::vector<std::string> &target_names, const SplitParams &params,
                            std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
+
+// The same in two halves: prepare() needs no alignment intervals (primaries / supplementaries, the map's iteration order, survivors) and may
+// run while the scan kernel's outputs are still being produced; finish() does the rest. `contigs` and `target_names` must outlive the object.
+class SplitPass {
+public:
+    SplitPass(const std::vector<SplitContig> &contigs, const std::vector<std::string> &target_names, const SplitParams &params);
+    ~SplitPass();
+    void prepare();
+    void finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
+private:
+    struct Impl;
+    std::unique_ptr<Impl> p;
+    bool prepared = false;
+};
 
 // Same, from records in file order (any mix of tids) and their names as strings.
 void findSplitSVSignatures(const std::vector<SplitRecord> &records, const std::vector<std::string> &qnames,

@@ -359,6 +359,21 @@ struct ShardOrderSource : SplitOrderSource {
     std::vector<csv_shard *> shard_of;
 };
 
+}  // namespace
+
+// what the split-read pass of a run works on (built once per run; prepare() may already be running while the CIGAR pass is on the device)
+struct SVCaller::SplitSetup {
+    std::vector<SplitContig> blocks;
+    std::vector<std::string> names;
+    std::unique_ptr<ShardOrderSource> dev_order;
+    std::unique_ptr<ShardIntervals> intervals;
+    SplitParams sp;
+    std::unique_ptr<SplitPass> pass;
+    double ms_prepare = 0.0;
+    std::exception_ptr err;
+};
+
+namespace {
 struct EmptySnps : SNPSource {
     void query(uint32_t, uint32_t, std::vector<uint32_t> &, std::unordered_map<uint32_t, double> &, std::unordered_map<uint32_t, double> &) const override {}
 };
@@ -447,6 +462,25 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     const size_t n = contigs.size();
     std::vector<ChrStats> stats(n);
     std::vector<std::vector<SVCall>> per(n);
+    // The first half of the split-read pass needs nothing the CIGAR pass produces (flags, name hashes -> the qname map's iteration order):
+    // with lanes, this caller's own context is idle during the CIGAR pass, so that half runs beside it on another thread.
+    std::unique_ptr<SplitSetup> split;
+    csvhost::WorkerThreads::Ticket split_task = nullptr;
+    if (P.split_svs) {
+        split = makeSplitSetup(contigs, P);
+        if (P.cigar_svs && n && lane_ctxs.size() > 1) {
+            SplitSetup *S = split.get();
+            split_task = csvhost::WorkerThreads::instance().start([S] {
+                const double t0 = now_ms();
+                try { S->pass->prepare(); } catch (...) { S->err = std::current_exception(); }
+                S->ms_prepare = now_ms() - t0;
+            });
+        }
+    }
+    struct JoinSplit {                                                  // the task refers to `split`: never leave this frame with it running
+        csvhost::WorkerThreads::Ticket &t;
+        ~JoinSplit() { if (t) { csvhost::WorkerThreads::instance().wait(t); t = nullptr; } }
+    } join_split{split_task};
     if (P.cigar_svs && n) {
         // contigs over the lanes: longest processing time first by read count, every lane works down its list
         const size_t L = std::max<size_t>(1, lane_ctxs.size());
@@ -483,14 +517,38 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         whole_genome_sv_calls[contigs[i].name] = std::move(per[i]);
     }
     T.ms_cigar = now_ms() - t_begin;
-    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T);
+    if (split_task) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
+    if (split && split->err) std::rethrow_exception(split->err);
+    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get());
     T.ms_total = now_ms() - t_begin;
     if (stats_out) *stats_out = stats;
     if (times) *times = T;
 }
 
+std::unique_ptr<SVCaller::SplitSetup> SVCaller::makeSplitSetup(std::vector<ResidentContig> &contigs, const RunParams &P)
+{
+    std::unique_ptr<SplitSetup> S(new SplitSetup());
+    std::vector<csv_shard *> shard_of;
+    for (size_t i = 0; i < contigs.size(); i++) {
+        ResidentContig &c = contigs[i];
+        S->names.push_back(c.name);
+        if (!c.split.qhash || !c.shard || !c.split.n) continue;
+        c.split.tid = (int32_t)i;
+        c.split.ref_end = c.split.q_start = c.split.q_end = nullptr;     // the scan kernel's per-read intervals (the reference's third BAM pass, :137-172) stay in the shards
+        S->blocks.push_back(c.split);
+        shard_of.push_back(c.shard);
+    }
+    S->sp.min_mapq = min_mapq; S->sp.threads = P.host_threads;
+    S->dev_order.reset(new ShardOrderSource(ctx, shard_of));
+    S->intervals.reset(new ShardIntervals(ctx, shard_of));
+    S->sp.intervals = S->intervals.get();
+    if (P.split_order_on_device) S->sp.device_order = S->dev_order.get();          // only contigs staged with unique_names take it
+    S->pass.reset(new SplitPass(S->blocks, S->names, S->sp));
+    return S;
+}
+
 void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
-                         std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T)
+                         std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split)
 {
     const EmptySnps no_snps;
     std::unordered_map<std::string, size_t> index_of;
@@ -525,27 +583,12 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
     T.ms_cigar_cn = now_ms() - t0;
     if (P.split_svs) {                                                             // :885-917
         t0 = now_ms();
-        // the scan kernel's per-read intervals (the reference's third BAM pass, :137-172) stay in the shards: the pass gathers the
-        // few records it needs (ShardIntervals)
-        std::vector<SplitContig> blocks;
-        for (size_t i = 0; i < contigs.size(); i++) {
-            ResidentContig &c = contigs[i];
-            if (!c.split.qhash || !c.shard || !c.split.n) continue;
-            c.split.tid = (int32_t)i;
-            c.split.ref_end = c.split.q_start = c.split.q_end = nullptr;
-            blocks.push_back(c.split);
-        }
-        T.ms_split_fetch = now_ms() - t0;
-        t0 = now_ms();
+        std::unique_ptr<SplitSetup> own;
+        if (!split) { own = makeSplitSetup(contigs, P); split = own.get(); }
+        T.ms_split_fetch = 0.0;
         std::unordered_map<std::string, std::vector<SVCall>> split_calls;
-        SplitParams sp; sp.min_mapq = min_mapq; sp.threads = P.host_threads;
-        std::vector<csv_shard *> shard_of;
-        for (const SplitContig &b : blocks) shard_of.push_back(contigs[(size_t)b.tid].shard);
-        const ShardOrderSource dev_order(ctx, shard_of);
-        const ShardIntervals intervals(ctx, shard_of);
-        sp.intervals = &intervals;
-        if (P.split_order_on_device) sp.device_order = &dev_order;                 // only contigs staged with unique_names take it
-        findSplitSVSignatures(blocks, names, sp, split_calls);
+        split->pass->finish(split_calls);                                          // (runs prepare() first when nobody has)
+        T.ms_split_prepare = split->ms_prepare;
         T.ms_split = now_ms() - t0;
         t0 = now_ms();
         {

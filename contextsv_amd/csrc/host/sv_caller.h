@@ -5,6 +5,7 @@
 // C-ABI; the host keeps only the order-defining representative choice (mergeSVs) and the string fields.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -68,7 +69,8 @@ struct RunStageTimes {
     double ms_cigar = 0;        // depth + CIGAR scan + ordering + DBSCAN + mergeSVs, all contigs
     double ms_cigar_cn = 0;     // runCIGARCopyNumberPrediction, all contigs
     double ms_split_fetch = 0;  // alignment intervals device -> host
-    double ms_split = 0;        // findSplitSVSignatures
+    double ms_split = 0;        // findSplitSVSignatures (its second half when the first ran beside the CIGAR pass)
+    double ms_split_prepare = 0; // its first half — primaries / supplementaries, the qname map's order, survivors; inside ms_cigar's wall time when lanes are used
     double ms_split_cn = 0;     // runSplitReadCopyNumberPredictions
     double ms_merge_split = 0;  // mergeSVs(0.1, 2, true) on the split calls + concatenation
     double ms_merge_final = 0;  // mergeSVs(0.1, 2, true) on the union
@@ -170,8 +172,10 @@ private:
     csv_ctx *ctx;
     // everything of run() behind the CIGAR pass: CIGAR copy-number predictions, split-read signatures + their predictions, the two
     // final merges, the VCF (sv_caller.cpp:865-945). stats[i] belongs to contigs[i].
+    struct SplitSetup;
+    std::unique_ptr<SplitSetup> makeSplitSetup(std::vector<ResidentContig> &contigs, const RunParams &P);
     void finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
-                   std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T);
+                   std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split = nullptr);
     struct DeviceOut {                       // what the device chain of one shard hands to the host merge: page-locked result buffers
         csv_ctx *ctx = nullptr;
         csv_sig *sig = nullptr;

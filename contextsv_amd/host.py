@@ -29,7 +29,7 @@ class bam_stats(C.Structure):
 
 class stage_times(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("ms_cigar", "ms_cigar_cn", "ms_split_fetch", "ms_split", "ms_split_cn", "ms_merge_split", "ms_merge_final",
-                                          "ms_vcf", "ms_total")] + \
+                                          "ms_vcf", "ms_total", "ms_split_prepare")] + \
                [(k, C.c_uint64) for k in ("n_reads", "n_signatures", "n_cigar_calls", "n_cigar_cn_regions", "n_split_calls", "n_final_calls")]
 
 
