@@ -551,6 +551,11 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
                          std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split)
 {
     const EmptySnps no_snps;
+    csvhost::WorkerThreads::Ticket teardown = nullptr;
+    struct JoinTeardown {
+        csvhost::WorkerThreads::Ticket &t;
+        ~JoinTeardown() { if (t) csvhost::WorkerThreads::instance().wait(t); }
+    } join_teardown{teardown};
     std::unordered_map<std::string, size_t> index_of;
     std::vector<std::string> names;
     for (size_t i = 0; i < contigs.size(); i++) { index_of[contigs[i].name] = i; names.push_back(contigs[i].name); }
@@ -589,6 +594,10 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         std::unordered_map<std::string, std::vector<SVCall>> split_calls;
         split->pass->finish(split_calls);                                          // (runs prepare() first when nobody has)
         T.ms_split_prepare = split->ms_prepare;
+        {   // the pass's working set (1e5 small vectors for a genome) is torn down beside the next stages, not between them
+            std::shared_ptr<SplitPass> dead(split->pass.release());
+            teardown = csvhost::WorkerThreads::instance().start([dead]() mutable { dead.reset(); });
+        }
         T.ms_split = now_ms() - t0;
         t0 = now_ms();
         {
