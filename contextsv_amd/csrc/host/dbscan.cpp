@@ -10,6 +10,7 @@
 
 namespace {
 csv_ctx *g_ctx = nullptr;
+thread_local csv_ctx *t_ctx = nullptr;
 std::mutex g_print;
 bool g_quiet = false;
 }
@@ -20,8 +21,10 @@ void printError(const std::string &m) { std::lock_guard<std::mutex> l(g_print); 
 namespace csvhost {
 void set_quiet(bool q) { g_quiet = q; }
 void set_context(csv_ctx *ctx) { g_ctx = ctx; }
+void set_thread_context(csv_ctx *ctx) { t_ctx = ctx; }
 csv_ctx *context()
 {
+    if (t_ctx) return t_ctx;
     if (!g_ctx) throw std::runtime_error("csvhost: no GPU context set (csvhost::set_context) — the clustering path has no CPU fallback");
     return g_ctx;
 }

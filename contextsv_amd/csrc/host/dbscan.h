@@ -9,6 +9,7 @@
 
 namespace csvhost {
 void set_context(csv_ctx *ctx);      // borrowed, not owned
+void set_thread_context(csv_ctx *ctx);   // this thread's own context (nullptr: the process-wide one): a context serves one host thread at a time
 csv_ctx *context();                  // throws std::runtime_error when unset (there is no CPU fallback)
 }
 

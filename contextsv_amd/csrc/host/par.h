@@ -29,11 +29,14 @@ struct TraceScope {
 
 class HostPool {
 public:
+    // Two pools: a thread that has called use_second_pool() gets the second one, so that two independent chains of a run (the CIGAR
+    // copy-number pass and the split-read chain) can each keep their parallel sections parallel while they run side by side.
     static HostPool &instance()
     {
-        static HostPool p;
-        return p;
+        static HostPool p[2];
+        return p[second_pool_flag() ? 1 : 0];
     }
+    static bool &second_pool_flag() { static thread_local bool f = false; return f; }
 
     // f(i) for every i in [0, n), on up to `threads` threads (0: all of the pool's), the caller's included; returns when all are done.
     // Items are handed out one at a time in index order (put the heavy ones first). The first exception is rethrown here.

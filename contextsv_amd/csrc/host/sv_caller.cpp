@@ -519,7 +519,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     T.ms_cigar = now_ms() - t_begin;
     if (split_task) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
     if (split && split->err) std::rethrow_exception(split->err);
-    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get());
+    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get(), lane_ctxs.size() > 1 ? lane_ctxs[0] : nullptr);
     T.ms_total = now_ms() - t_begin;
     if (stats_out) *stats_out = stats;
     if (times) *times = T;
@@ -548,7 +548,7 @@ std::unique_ptr<SVCaller::SplitSetup> SVCaller::makeSplitSetup(std::vector<Resid
 }
 
 void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
-                         std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split)
+                         std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split, csv_ctx *side_ctx)
 {
     const EmptySnps no_snps;
     csvhost::WorkerThreads::Ticket teardown = nullptr;
@@ -580,12 +580,37 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         }
         return jobs;
     };
-    if (P.cigar_svs && P.cigar_cn) {                                               // :865-881
+    // The CIGAR copy-number pass (:865-881) and the split-read chain (:885-917) do not depend on each other: with a second context
+    // at hand (`side_ctx`: a lane's, idle by now) the former runs on another thread — its own context, its own host pool — while
+    // this thread goes on with the latter; they meet in front of the final merge.
+    csvhost::WorkerThreads::Ticket cn_task = nullptr;
+    std::exception_ptr cn_err;
+    struct JoinCn {
+        csvhost::WorkerThreads::Ticket &t;
+        ~JoinCn() { if (t) csvhost::WorkerThreads::instance().wait(t); }
+    } join_cn{cn_task};
+    if (P.cigar_svs && P.cigar_cn) {
         printMessage("Running copy number predictions on CIGAR SVs...");
-        std::vector<CNVCaller::ContigJob> jobs = cn_jobs(whole_genome_sv_calls);
-        T.n_cigar_cn_regions += cnv.runCIGARCopyNumberPredictionAll(jobs, hmm);
+        if (side_ctx && side_ctx != ctx && P.split_svs && !cnv.save_cnv_data) {
+            cn_task = csvhost::WorkerThreads::instance().start([&, t0] {
+                try {
+                    csvhost::HostPool::second_pool_flag() = true;
+                    csvhost::set_thread_context(side_ctx);
+                    CNVCaller side(side_ctx);
+                    side.sample_size = cnv.sample_size; side.min_cnv_length = cnv.min_cnv_length; side.host_threads = cnv.host_threads;
+                    std::vector<CNVCaller::ContigJob> jobs = cn_jobs(whole_genome_sv_calls);
+                    T.n_cigar_cn_regions += side.runCIGARCopyNumberPredictionAll(jobs, hmm);
+                } catch (...) { cn_err = std::current_exception(); }
+                csvhost::set_thread_context(nullptr);
+                csvhost::HostPool::second_pool_flag() = false;
+                T.ms_cigar_cn = now_ms() - t0;
+            });
+        } else {
+            std::vector<CNVCaller::ContigJob> jobs = cn_jobs(whole_genome_sv_calls);
+            T.n_cigar_cn_regions += cnv.runCIGARCopyNumberPredictionAll(jobs, hmm);
+            T.ms_cigar_cn = now_ms() - t0;
+        }
     }
-    T.ms_cigar_cn = now_ms() - t0;
     if (P.split_svs) {                                                             // :885-917
         t0 = now_ms();
         std::unique_ptr<SplitSetup> own;
@@ -611,6 +636,8 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
             for (auto &entry : split_calls) sets.push_back(&entry.second);
             mergeSVsMany(sets, 0.1, 2, true, P.host_threads);
         }
+        if (cn_task) { csvhost::WorkerThreads::instance().wait(cn_task); cn_task = nullptr; }          // the CIGAR calls are final from here on
+        if (cn_err) std::rethrow_exception(cn_err);
         for (auto &entry : split_calls) {
             T.n_split_calls += entry.second.size();
             std::vector<SVCall> &dst = whole_genome_sv_calls[entry.first];
@@ -618,6 +645,8 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         }
         T.ms_merge_split = now_ms() - t0;
     }
+    if (cn_task) { csvhost::WorkerThreads::instance().wait(cn_task); cn_task = nullptr; }
+    if (cn_err) std::rethrow_exception(cn_err);
     t0 = now_ms();
     if (P.merge_final_svs) {                                                                                 // :919-927
         std::vector<std::vector<SVCall> *> sets;

@@ -67,7 +67,7 @@ struct ResidentContig {
 // Wall time of each pass of one run (the order of SVCaller::run, sv_caller.cpp:804-945) and what went through it.
 struct RunStageTimes {
     double ms_cigar = 0;        // depth + CIGAR scan + ordering + DBSCAN + mergeSVs, all contigs
-    double ms_cigar_cn = 0;     // runCIGARCopyNumberPrediction, all contigs
+    double ms_cigar_cn = 0;     // runCIGARCopyNumberPrediction, all contigs (with lanes: beside the split-read chain, on a lane's context)
     double ms_split_fetch = 0;  // alignment intervals device -> host
     double ms_split = 0;        // findSplitSVSignatures (its second half when the first ran beside the CIGAR pass)
     double ms_split_prepare = 0; // its first half — primaries / supplementaries, the qname map's order, survivors; inside ms_cigar's wall time when lanes are used
@@ -175,7 +175,8 @@ private:
     struct SplitSetup;
     std::unique_ptr<SplitSetup> makeSplitSetup(std::vector<ResidentContig> &contigs, const RunParams &P);
     void finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
-                   std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split = nullptr);
+                   std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split = nullptr,
+                   csv_ctx *side_ctx = nullptr);
     struct DeviceOut {                       // what the device chain of one shard hands to the host merge: page-locked result buffers
         csv_ctx *ctx = nullptr;
         csv_sig *sig = nullptr;
