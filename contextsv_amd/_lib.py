@@ -51,6 +51,7 @@ class csv_chr_result(C.Structure):
 _P = C.c_void_p
 ABI = {
     "csvgpu_create": (_P, [C.c_int, _P]),
+    "csvgpu_create_background": (_P, [C.c_int]),
     "csvgpu_destroy": (None, [_P]),
     "csvgpu_abi_version": (C.c_int, []),
     "csvgpu_last_error": (C.c_char_p, [_P]),

@@ -79,9 +79,9 @@ class Gate:
 class Context:
     """One csv_ctx (= one GPU). `stream` may be an existing hipStream_t handle (e.g. torch's)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, background: bool = False):
         self.lib = _lib.load()
-        self.h = self.lib.csvgpu_create(device, stream)
+        self.h = self.lib.csvgpu_create_background(device) if background else self.lib.csvgpu_create(device, stream)
         if not self.h:
             msg = self.lib.csvgpu_last_error(None)
             raise CsvError(_lib.CSV_ENODEV, (msg or b"csvgpu_create failed").decode())

@@ -370,7 +370,11 @@ int csvgpu_abi_version(void) { return CSVGPU_ABI_VERSION; }
 
 const char *csvgpu_last_error(const csv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-csv_ctx *csvgpu_create(int device_ordinal, void *stream)
+static csv_ctx *create_ctx(int device_ordinal, void *stream, int low_priority);
+csv_ctx *csvgpu_create(int device_ordinal, void *stream) { return create_ctx(device_ordinal, stream, 0); }
+csv_ctx *csvgpu_create_background(int device_ordinal) { return create_ctx(device_ordinal, nullptr, 1); }
+
+static csv_ctx *create_ctx(int device_ordinal, void *stream, int low_priority)
 {
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
@@ -386,7 +390,10 @@ csv_ctx *csvgpu_create(int device_ordinal, void *stream)
     ctx->device = device_ordinal;
     if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete ctx; return nullptr; }
+        int least = 0, greatest = 0;
+        if (low_priority) (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const hipError_t se = low_priority ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete ctx; return nullptr; }
         ctx->own_stream = true;
     }
     hipDeviceProp_t prop;

@@ -298,6 +298,9 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                     const uint32_t n_more = (uint32_t)__popcll(__ballot(la != 0xffffffffu && p1rel + (int32_t)la < TW));
                     if (n_more < (uint32_t)WAVE) n_chunks = min(n_chunks, n_more + 1u);
                 }
+                // DEPTH_PF + 1 chunk buffers used as a ring with STATIC indices: the chunk loop is unrolled by the ring's size, so a buffer
+                // is refilled in place the moment its words have been decoded (rotating the buffers cost 12 register moves per chunk,
+                // a sixth of the loop's vector instructions).
                 uint32_t w[DEPTH_PF + 1][4];
 #pragma unroll
                 for (int j = 0; j <= DEPTH_PF; j++) {
@@ -306,46 +309,45 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                     if ((uint32_t)j < n_chunks) load_chunk((uint32_t)j * (4 * WAVE), w[j]);
                 }
                 if (it_next < n_items) la_next = look_ahead(it_next);                // in flight during this walk
-                for (uint32_t c = 0;; c++) {
-                    const uint32_t o0 = c * (4 * WAVE);                             // word offset of this chunk from chunk0
-                    uint32_t nw[4] = {0, 0, 0, 0};
-                    if (c + DEPTH_PF + 1 < n_chunks) load_chunk(o0 + (DEPTH_PF + 1) * (4 * WAVE), nw);
-                    uint32_t (&cur)[4] = w[0];
-                    // only the first and the last chunk of an item can hold words of a neighbouring read
-                    if (!((int32_t)o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
-                        const int32_t o = (int32_t)o0 + lane * 4;
+                bool walking = true;
+                for (uint32_t c0 = 0; walking; c0 += DEPTH_PF + 1) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) if (!((o + k >= c0rel) && ((uint32_t)(o + k) < nrem))) cur[k] = (uint32_t)OP_P;
-                    }
-                    uint32_t rl[4], al[4], lane_ref = 0;
+                    for (int j = 0; j <= DEPTH_PF; j++) {
+                        if (!walking) break;
+                        const uint32_t c = c0 + (uint32_t)j;
+                        const uint32_t o0 = c * (4 * WAVE);                         // word offset of this chunk from chunk0
+                        uint32_t (&cur)[4] = w[j];
+                        // only the first and the last chunk of an item can hold words of a neighbouring read
+                        if (!((int32_t)o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
+                            const int32_t o = (int32_t)o0 + lane * 4;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        // v_bfe_i32 takes its bit offset from the word's low five bits (op + the length's lowest bit): op masks repeated at bit 16
-                        const uint32_t len = cur[k] >> 4;
-                        rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), cur[k], 1u);    // all-ones when the op consumes the reference
-                        al[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(ALN_OPS | (ALN_OPS << 16)), cur[k], 1u);    // ... when its bases count toward depth
-                        lane_ref += rl[k];
-                    }
-                    const uint32_t incl = wave_incl_sum_dpp(lane_ref);
-                    int32_t rel = base_rel + (int32_t)(incl - lane_ref);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int32_t a = max(rel, 0), b = min(rel + (int32_t)al[k], TW);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
-                        if (a < b) {
-                            atomicAdd(&diff[a], 1u);
-                            atomicAdd(&diff[b], 0xffffffffu);
+                            for (int k = 0; k < 4; k++) if (!((o + k >= c0rel) && ((uint32_t)(o + k) < nrem))) cur[k] = (uint32_t)OP_P;
                         }
-                        rel += (int32_t)rl[k];
+                        uint32_t rl[4], al[4], lane_ref = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            // v_bfe_i32 takes its bit offset from the word's low five bits (op + the length's lowest bit): op masks repeated at bit 16
+                            const uint32_t len = cur[k] >> 4;
+                            rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), cur[k], 1u);    // all-ones when the op consumes the reference
+                            al[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(ALN_OPS | (ALN_OPS << 16)), cur[k], 1u);    // ... when its bases count toward depth
+                            lane_ref += rl[k];
+                        }
+                        // the buffer's words are decoded: refill it with the chunk DEPTH_PF + 1 ahead
+                        if (c + DEPTH_PF + 1 < n_chunks) load_chunk(o0 + (DEPTH_PF + 1) * (4 * WAVE), w[j]);
+                        const uint32_t incl = wave_incl_sum_dpp(lane_ref);
+                        int32_t rel = base_rel + (int32_t)(incl - lane_ref);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int32_t a = max(rel, 0), b = min(rel + (int32_t)al[k], TW);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
+                            if (a < b) {
+                                atomicAdd(&diff[a], 1u);
+                                atomicAdd(&diff[b], 0xffffffffu);
+                            }
+                            rel += (int32_t)rl[k];
+                        }
+                        base_rel += (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        if (c + 1 >= n_chunks || base_rel >= TW) walking = false;   // the read ends here, or the rest of it lies right of the tile
                     }
-                    base_rel += (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    if (c + 1 >= n_chunks || base_rel >= TW) break;                 // the read ends here, or the rest of it lies right of the tile
-#pragma unroll
-                    for (int j = 0; j < DEPTH_PF; j++) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) w[j][k] = w[j + 1][k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) w[DEPTH_PF][k] = nw[k];
                 }
             }
             it = it_next; la = la_next;

@@ -109,6 +109,9 @@ typedef enum csv_kernel_id {
  * every kernel of this context is then launched on. Returns NULL on failure (no device, ...);
  * csvgpu_last_error(NULL) then describes why. */
 csv_ctx    *csvgpu_create(int device_ordinal, void *stream);
+/* The same with the context's own stream at the device's LOWEST priority: for work that should fill the gaps other contexts leave (the
+ * split-read pass's ordering kernels beside the lanes' bandwidth-bound pairs) instead of sharing the compute units with them. */
+csv_ctx    *csvgpu_create_background(int device_ordinal);
 void        csvgpu_destroy(csv_ctx *ctx);
 int         csvgpu_abi_version(void);
 const char *csvgpu_last_error(const csv_ctx *ctx);
