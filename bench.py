@@ -289,6 +289,12 @@ def main():
             out["verify"] = verify
         if world == 1 and not args.no_legs:
             out["chr1_cnv"] = leg_chr1(cs, host, ctx, lane_ctx, genome, info, hmm, args)
+            # the same kernel with the device to itself (the chr1 leg runs one contig on one context: nothing beside the scan / depth pair)
+            alone = out["chr1_cnv"].get("depth_GBps" if dominant == "depth" else "cigar_scan_GBps")
+            if alone:
+                out["roofline"]["alone_frac"] = alone / HBM_PEAK_GBS
+                out["roofline"]["note"] += ("; in the genome step the split-read pass's ordering kernels share the device with the first half of the CIGAR pass "
+                                            "(that overlap is worth ~10 % of the step and stretches the big kernels by ~6 %): `alone_frac` is the same kernel on chr1 with nothing beside it")
             out["chr22_cigar_path"] = leg_chr22(cs, host, dev, args, tech, config_id, gen_threads)
             if not args.no_from_file:
                 out["from_file"] = from_file(cs, host, ctx, args, tech, config_id, gen_threads)

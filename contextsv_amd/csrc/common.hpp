@@ -217,6 +217,7 @@ struct SplitOrderTab {                       // passed to the kernels by value
     uint64_t blk_off[SO_MAX_CONTIGS + 1];    // compaction: first 1024-record block of each contig
     uint64_t work_off[SO_MAX_CONTIGS + 1];   // epoch: first work item (node present in the epoch) of each active contig
     uint32_t nbase[SO_MAX_CONTIGS + 1];      // global index of each contig's first node
+    uint64_t rev_off[SO_MAX_CONTIGS];        // epoch: work items of the active contigs BEHIND this one (the sort key's contig part)
     uint32_t m_old[SO_MAX_CONTIGS];          // epoch: nodes that were in the list when the epoch began (the rest were inserted during it)
     uint64_t n_reads[SO_MAX_CONTIGS];
     const uint16_t *flag[SO_MAX_CONTIGS];

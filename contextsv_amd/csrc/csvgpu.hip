@@ -1125,7 +1125,8 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         if (m_max <= 1) continue;                                                   // a single node: nothing to order
         const uint32_t B = (uint32_t)buckets[k];
         const int wbits = std::max(1, bits_of(m_max - 1));
-        const int key_bits = wbits + std::max(1, bits_of((uint64_t)e.A - 1));
+        for (uint32_t a = 0; a < e.A; a++) e.rev_off[a] = M - e.work_off[a + 1];
+        const int key_bits = std::max(1, bits_of(M - 1));
         CSV_HIP(ctx, hipMemsetAsync(minT, 0xff, (size_t)e.A * B * 4, s));
         launch_so_mint(s, e, M, B, node_hash, list, minT);
         launch_so_keys(s, e, M, B, wbits, node_hash, list, minT, w.k0, w.v0);

@@ -9,7 +9,7 @@
 // then the list at the end of the epoch is the nodes sorted by (min t of the node's bucket, descending; t, descending).
 // So the order of N keys is a chain of ~log2(N) stable sorts of geometrically growing size (~2N keys sorted in all), each of them:
 //   so_mint   minT[bucket] = min t            (atomicMin; bucket = hash % B, B from the library's own _Prime_rehash_policy)
-//   so_keys   key = contig | ~minT, items enumerated in descending t (all contigs of the genome share every launch)
+//   so_keys   key = one number for (contig, ~minT), items enumerated in descending t (all contigs of the genome share every launch)
 //   stable radix sort (sort.hip), so_setlist    the new list
 // and the survivors (nodes whose name hash is among the supplementary records' hashes) leave with their final position.
 // Checked against umap_order.h (which is checked against the real container) in tests/test_gpu_split_order.py.
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_scatter_kernel(SplitOrderTab ta
 // Work item j of active contig a enumerates the contig's present nodes in DESCENDING processing time t: the nodes that were in the list
 // when the epoch began sit at t = their list position (list[]), the ones inserted during the epoch at t = their insertion index (which is
 // also their node index). A STABLE sort of the items by (contig, bucket time descending) then leaves every bucket's nodes in descending
-// own time without t being part of the key: four 8-bit passes instead of six.
+// own time without t being part of the key: three 8-bit passes instead of six.
 __device__ __forceinline__ uint32_t so_node_at(const SplitOrderTab &tab, uint32_t a, uint32_t t, const uint32_t *__restrict__ list)
 {
     return tab.nbase[a] + (t < tab.m_old[a] ? list[tab.nbase[a] + t] : t);
@@ -115,8 +115,10 @@ __global__ __launch_bounds__(SO_THREADS) void so_keys_kernel(SplitOrderTab tab, 
     const uint32_t t = m - 1u - (uint32_t)(j - tab.work_off[a]);
     const uint32_t g = so_node_at(tab, a, t, list);
     const uint32_t b = (uint32_t)(node_hash[g] % (uint64_t)B);
-    const uint64_t mask = (1ull << w) - 1ull;
-    keys[j] = ((uint64_t)a << w) | (mask - (uint64_t)minT[(uint64_t)a * B + b]);      // ascending: contig, then LARGER bucket time first
+    // One number orders contig and bucket time together: rev_off[a] = items of the contigs behind a, so contig 0 owns the largest
+    // values and, sorted descending (ascending in M - 1 - x), comes first, its buckets with the LARGER time first. bits(M - 1) <= 23
+    // for a genome: three 8-bit passes.
+    keys[j] = (M - 1ull) - (tab.rev_off[a] + (uint64_t)minT[(uint64_t)a * B + b]);
     vals[j] = g - tab.nbase[a];                                                        // node index inside its contig
 }
 
