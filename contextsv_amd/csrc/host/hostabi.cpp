@@ -18,7 +18,10 @@
 #include "bam_io.h"
 #include "snp_io.h"
 #include "fast_inflate.h"
+#include "par.h"
 #include "umap_order.h"
+#include <atomic>
+#include <thread>
 #include <fstream>
 #include <memory>
 #include <algorithm>
@@ -335,6 +338,44 @@ int csvhost_string_hashes(const char *names, uint64_t n, uint64_t *out)
             const size_t len = e ? (size_t)(e - p) : strlen(p);
             out[i] = csvhost::std_string_hash(p, len);
             p = e ? e + 1 : p + len;
+        }
+    })
+}
+
+// Test hook for par.h (CPU): parallel_for visits every index exactly once whatever the thread count, runs nested sections inline, hands
+// the first exception to the caller and stays usable; WorkerThreads runs tasks side by side and reuses its threads. 0 = all held.
+int csvhost_par_selftest(int n_items, int threads)
+{
+    GUARD({
+        std::vector<std::atomic<int>> hit((size_t)n_items);
+        for (auto &h : hit) h = 0;
+        csvhost::parallel_for((size_t)n_items, threads, [&](size_t i) {
+            hit[i]++;
+            csvhost::parallel_for(3, threads, [&](size_t) {});                     // nested: inline
+        });
+        for (auto &h : hit) if (h != 1) throw std::runtime_error("parallel_for: an index was not visited exactly once");
+        bool thrown = false;
+        try { csvhost::parallel_for((size_t)n_items, threads, [&](size_t i) { if (i == (size_t)n_items / 2) throw std::runtime_error("x"); }); }
+        catch (const std::runtime_error &) { thrown = true; }
+        if (!thrown && n_items > 0) throw std::runtime_error("parallel_for: exception lost");
+        std::atomic<long> sum{0};
+        csvhost::parallel_for((size_t)n_items, threads, [&](size_t i) { sum += (long)i; });
+        if (sum != (long)n_items * (n_items - 1) / 2) throw std::runtime_error("parallel_for: wrong sum after an exception");
+        csvhost::WorkerThreads &w = csvhost::WorkerThreads::instance();
+        for (int round = 0; round < 3; round++) {
+            std::atomic<int> inside{0}, peak{0};
+            std::vector<csvhost::WorkerThreads::Ticket> t;
+            for (int k = 0; k < 4; k++)
+                t.push_back(w.start([&] {
+                    const int now = ++inside;
+                    int p = peak.load();
+                    while (now > p && !peak.compare_exchange_weak(p, now)) {}
+                    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+                    while (std::chrono::steady_clock::now() < until && peak.load() < 4) std::this_thread::yield();
+                    --inside;
+                }));
+            for (auto x : t) w.wait(x);
+            if (peak != 4) throw std::runtime_error("WorkerThreads: tasks did not run side by side");
         }
     })
 }

@@ -136,6 +136,7 @@ def load() -> C.CDLL:
                                        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(stage_times), _P]
     lib.csvhost_sig_alts.argtypes = [_P, C.c_uint64, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_process_resident_chromosome_alts.argtypes = [_P, _P, _P, _P, C.c_double, C.c_double, _P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.csvhost_par_selftest.argtypes = [C.c_int, C.c_int]
     lib.csvhost_string_hashes.argtypes = [C.c_char_p, C.c_uint64, _P]
     lib.csvhost_set_quiet(1)
     _hlib = lib
