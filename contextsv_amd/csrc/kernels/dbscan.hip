@@ -452,7 +452,7 @@ __device__ __forceinline__ bool ivs_nb(uint32_t s1, uint32_t e1, uint32_t s2, ui
     return iv_neighbor(s1, e1, s2, e2, eps);
 }
 
-constexpr int IVS_THREADS = 256;
+constexpr int IVS_THREADS = 1024;      // a launch lasts as long as its largest set: 16 waves share that set's n^2 pair tests
 constexpr int IVS_MAX = (int)DBSCAN_IV_SMALL_MAX;
 
 __global__ __launch_bounds__(IVS_THREADS) void dbscan_iv_small_kernel(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end,
