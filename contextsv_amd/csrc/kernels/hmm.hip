@@ -205,12 +205,15 @@ __global__ void hmm_emit_kernel(const HmmDev *__restrict__ d, const double *__re
 }
 
 constexpr int VIT_GROUPS = 10;    // sequences per wave (6 lanes each, 4 lanes idle)
+constexpr int VIT_LDS_T = 512;    // back-pointers of sequences up to this length stay in LDS (30 KiB per wave): the backtrack is T dependent
+                                  // look-ups by one lane, ~1 us apiece from global memory, tens of ns from LDS; a copy-number pass has T ~ 25
 
 __global__ __launch_bounds__(64) void hmm_viterbi_kernel(const HmmDev *__restrict__ d, const double *__restrict__ biot,
                                                         const uint64_t *__restrict__ seq_off, uint64_t n_seq,
                                                         uint8_t *__restrict__ psi, int32_t *__restrict__ states,
                                                         double *__restrict__ loglik)
 {
+    __shared__ uint8_t lpsi[VIT_GROUPS][VIT_LDS_T][6];
     const int lane = lane_id();
     const int g = lane / 6, j = lane % 6;
     const uint64_t s = (uint64_t)blockIdx.x * VIT_GROUPS + g;
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(64) void hmm_viterbi_kernel(const HmmDev *__restric
     int64_t Tmax = T;
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) Tmax = max(Tmax, (int64_t)__shfl_xor((long long)Tmax, dd, 64));
+    const bool in_lds = Tmax <= (int64_t)VIT_LDS_T;                          // wave-uniform
     double la[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) la[i] = d->logA[i * 6 + j];
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(64) void hmm_viterbi_kernel(const HmmDev *__restric
         }
         if (live && t < T) {
             delta = maxval + biot[(a + t) * 6 + j];
-            psi[(a + t) * 6 + j] = (uint8_t)ind;
+            if (in_lds) lpsi[g][t][j] = (uint8_t)ind; else psi[(a + t) * 6 + j] = (uint8_t)ind;
         }
     }
     // termination (:362-371) and backtrack (:378-381) by the group's first lane
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(64) void hmm_viterbi_kernel(const HmmDev *__restric
         loglik[s] = final_lh;
         states[a + T - 1] = q;
         for (int64_t t = T - 2; t >= 0; t--) {
-            q = psi[(a + t + 1) * 6 + (q - 1)];
+            q = in_lds ? lpsi[g][t + 1][q - 1] : psi[(a + t + 1) * 6 + (q - 1)];
             states[a + t] = q;
         }
     }
