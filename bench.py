@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="contigs in flight per GPU during the CIGAR pass (contexts sharing a gate)")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads of the split-read / copy-number passes (0 = hardware)")
     ap.add_argument("--gen-threads", type=int, default=0, help="threads of the generator (0 = the CPU share of this rank, at most 32)")
+    ap.add_argument("--no-split-overlap", action="store_true", help="run the split-read pass's first half after the CIGAR pass instead of beside it (A/B: the big kernels "
+                    "then have the device to themselves)")
     ap.add_argument("--background", action="store_true", help="the caller's context at the LOWEST stream priority (csvgpu_create_background): the split pass's ordering "
                     "kernels then only fill the gaps of the CIGAR pass — measured: they no longer stretch the big kernels (depth 0.50 of peak instead of 0.48) but "
                     "finish 3.5 ms after the pass, 37.1 ms per step against 35.8")
@@ -154,7 +156,8 @@ def main():
     gather_cap = 1 << 16                                                  # merged calls per rank carried by the final gather (~27 k genome-wide)
 
     def step():
-        calls, tid, st, per = genome.run(ctx, hmm, lanes=lane_ctx, eps=args.eps, min_pts_pct=args.min_pts_pct, host_threads=args.host_threads, capacity=cap)
+        calls, tid, st, per = genome.run(ctx, hmm, lanes=lane_ctx, eps=args.eps, min_pts_pct=args.min_pts_pct, host_threads=args.host_threads, capacity=cap,
+                                         overlap_split=not args.no_split_overlap)
         gathered = None
         if world > 1:
             per_shard = {int(t): calls[tid == t] for t in np.unique(tid)}
@@ -287,6 +290,27 @@ def main():
         }
         if verify:
             out["verify"] = verify
+        if world == 1 and not args.no_legs and lane_ctx and not args.no_split_overlap:
+            # A/B of the one overlap that costs the big kernels something: the same steps with the split pass's first half AFTER the CIGAR pass
+            for c in lane_ctx:
+                c.timing_enable(3); c.timing_reset()
+            k2 = max(3, min(K, 10))
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                genome.run(ctx, hmm, lanes=lane_ctx, eps=args.eps, min_pts_pct=args.min_pts_pct, host_threads=args.host_threads, capacity=cap, overlap_split=False)
+            ctx.synchronize()
+            el2 = time.perf_counter() - t0
+            tm2 = {}
+            for c in lane_ctx:
+                for kk, (ms, n) in c.timing().items():
+                    a = tm2.get(kk, (0.0, 0)); tm2[kk] = (a[0] + ms, a[1] + n)
+                c.timing_enable(0)
+            d_ms = tm2.get(dominant, (0.0, 0))[0] / k2
+            out["no_split_overlap"] = {"value": reads_all * k2 / el2, "unit": "reads/s", "ms_per_step": el2 / k2 * 1e3, "steps": k2,
+                                       "kernel_ms_per_step": {kk: round(v[0] / k2, 4) for kk, v in tm2.items() if v[1]},
+                                       "roofline_frac": (alg_bytes[dominant] / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if d_ms > 0 else None,
+                                       "note": "the split-read pass's ordering kernels after the CIGAR pass instead of beside it: the big kernels have the device to "
+                                               "themselves (plus the lanes' own small kernels), the step is longer"}
         if world == 1 and not args.no_legs:
             out["chr1_cnv"] = leg_chr1(cs, host, ctx, lane_ctx, genome, info, hmm, args)
             # the same kernel with the device to itself (the chr1 leg runs one contig on one context: nothing beside the scan / depth pair)
@@ -294,7 +318,8 @@ def main():
             if alone:
                 out["roofline"]["alone_frac"] = alone / HBM_PEAK_GBS
                 out["roofline"]["note"] += ("; in the genome step the split-read pass's ordering kernels share the device with the first half of the CIGAR pass "
-                                            "(that overlap is worth ~10 % of the step and stretches the big kernels by ~6 %): `alone_frac` is the same kernel on chr1 with nothing beside it")
+                                            "(that overlap shortens the step by ~15 % and stretches the big kernels by ~12 %; `no_split_overlap` is the same genome without it): "
+                                            "`alone_frac` is the same kernel on chr1 with nothing beside it")
             out["chr22_cigar_path"] = leg_chr22(cs, host, dev, args, tech, config_id, gen_threads)
             if not args.no_from_file:
                 out["from_file"] = from_file(cs, host, ctx, args, tech, config_id, gen_threads)

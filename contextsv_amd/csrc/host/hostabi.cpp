@@ -628,7 +628,8 @@ void csvhost_genome_contig_info(const csvhost_genome *g, uint64_t i, uint64_t *n
 }
 
 // One step: SVCaller::runResident over every staged contig. passes: bit 0 split-read pass, bit 1 CIGAR copy-number pass, bit 2 the two
-// final merges, bit 3 keep the qname map's order on the host (umap_order.h) instead of csvgpu_split_order. Calls come back grouped by contig in staging order with the contig's GLOBAL tid in out_tid; stats[i] per contig.
+// final merges, bit 3 keep the qname map's order on the host (umap_order.h) instead of csvgpu_split_order,
+// bit 4 do not run the split pass's first half beside the CIGAR pass. Calls come back grouped by contig in staging order with the contig's GLOBAL tid in out_tid; stats[i] per contig.
 int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *const *lane_ctxs, const csv_hmm *hmm, double eps, double min_pts_pct,
                        int sample_size, uint32_t min_cnv, int passes, int host_threads, csvhost_call *out, int32_t *out_tid, uint64_t cap, uint64_t *n_out,
                        csvhost_stage_times *times, csvhost_chr_stats *stats)
@@ -645,6 +646,7 @@ int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *co
         P.split_svs = (passes & 1) != 0; P.cigar_cn = (passes & 2) != 0; P.merge_split_svs = P.merge_final_svs = (passes & 4) != 0;
         P.host_threads = host_threads;
         P.split_order_on_device = (passes & 8) == 0;
+        P.overlap_split_prepare = (passes & 16) == 0;
         std::vector<csv_ctx *> lanes(lane_ctxs, lane_ctxs + (n_lanes > 0 ? n_lanes : 0));
         SVCaller caller(ctx);
         std::unordered_map<std::string, std::vector<SVCall>> calls;

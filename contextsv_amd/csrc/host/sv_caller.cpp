@@ -468,7 +468,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     csvhost::WorkerThreads::Ticket split_task = nullptr;
     if (P.split_svs) {
         split = makeSplitSetup(contigs, P);
-        if (P.cigar_svs && n && lane_ctxs.size() > 1) {
+        if (P.cigar_svs && n && lane_ctxs.size() > 1 && P.overlap_split_prepare) {
             SplitSetup *S = split.get();
             split_task = csvhost::WorkerThreads::instance().start([S] {
                 const double t0 = now_ms();

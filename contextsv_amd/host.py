@@ -273,7 +273,7 @@ class Genome:
         return {"n_reads": nr.value, "n_cigar": nc.value, "depth_len": dl.value, "global_tid": gt.value, "shard": sh.value}
 
     def run(self, ctx: Context, hmm, lanes=None, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True, cigar_cn=True, merges=True,
-            host_threads=0, capacity: int = 1 << 20, host_split_order: bool = False):
+            host_threads=0, capacity: int = 1 << 20, host_split_order: bool = False, overlap_split: bool = True):
         """-> (calls[CALL_DTYPE], global tid per call, stage_times, per-contig chr_stats list)"""
         n = len(self)
         out = np.zeros(capacity, CALL_DTYPE)
@@ -284,7 +284,7 @@ class Genome:
         lanes = lanes or []
         lp = (C.c_void_p * max(len(lanes), 1))(*[c.h for c in lanes])
         _check(load().csvhost_genome_run(self.h, ctx.h, len(lanes), lp, C.byref(hmm), eps, min_pts_pct, sample_size, min_cnv,
-                                         int(split_svs) | (int(cigar_cn) << 1) | (int(merges) << 2) | (int(host_split_order) << 3), host_threads, out.ctypes.data, tid.ctypes.data, capacity,
+                                         int(split_svs) | (int(cigar_cn) << 1) | (int(merges) << 2) | (int(host_split_order) << 3) | (int(not overlap_split) << 4), host_threads, out.ctypes.data, tid.ctypes.data, capacity,
                                          C.byref(k), C.byref(st), cs))
         if k.value > capacity:
             raise RuntimeError("Genome.run: capacity too small")
