@@ -19,6 +19,9 @@ enum : uint32_t { F_UNMAP = 0x4, F_SECONDARY = 0x100, F_QCFAIL = 0x200, F_DUP = 
 constexpr uint32_t REF_OPS = (1u << OP_M) | (1u << OP_D) | (1u << OP_N) | (1u << OP_EQ) | (1u << OP_X);   // consume reference
 constexpr uint32_t QRY_OPS = (1u << OP_M) | (1u << OP_I) | (1u << OP_S) | (1u << OP_EQ) | (1u << OP_X);   // consume query
 constexpr uint32_t ALN_OPS = (1u << OP_M) | (1u << OP_EQ) | (1u << OP_X);                                  // count toward depth
+// words allocated behind an uploaded shard's CIGAR array, so that the kernels' 1 KiB chunk loads never need a bounds test
+constexpr uint32_t CIGAR_PAD_WORDS = 512;
+constexpr uint32_t GAP_OPS = REF_OPS & ~ALN_OPS;                                                             // D, N: on the reference, not in the depth
 constexpr uint32_t QST_OPS = (1u << OP_M) | (1u << OP_I) | (1u << OP_EQ) | (1u << OP_X);                   // open the query interval
 
 // ---------------------------------------------------------------------------------------------
@@ -74,6 +77,7 @@ struct csv_shard {
     csv_reads d;                   // device pointers
     uint32_t  depth_len = 0;
     bool      owned = false;       // true: arrays hipMalloc'd by csvgpu_shard_upload
+    uint32_t  cigar_pad = 0;       // allocated (zeroed) words behind d.cigar[n_cigar]: CIGAR_PAD_WORDS for the library's own uploads, 0 for wrapped arrays
     int       unsorted = -1;       // pos[] not non-decreasing: 1 / 0, or -1 while unknown (wrapped device arrays before their first scan)
     // per-read side arrays + per-chromosome outputs (device, owned by the shard)
     int32_t  *ref_end = nullptr, *q_start = nullptr, *q_end = nullptr, *pmax_end = nullptr;
@@ -86,6 +90,7 @@ struct csv_shard {
     char     *scratch = nullptr;   size_t scratch_cap = 0;   // sort / dbscan workspace
     uint64_t *counters = nullptr;  // device scalars (see ScanCounters) + bucket tables + the depth tiles' candidate ranges, zeroed together per chromosome
     uint64_t *tile_range = nullptr;   // inside `counters`
+    void     *depth_items = nullptr;  // depth_items_bytes(depth_len): the depth tiles' work lists (depth.hip)
     uint64_t *qhash = nullptr;        // [n_reads] std::hash<std::string> of every record's query name (csvgpu_shard_set_qname_hash), or null
     size_t    counters_bytes = 0;
 };
@@ -169,8 +174,10 @@ size_t depth_tiles_tmp_bytes(uint32_t depth_len);
 void launch_depth_ranges(hipStream_t s, const int32_t *pos_s, const int32_t *pmax_end, uint64_t n_reads, uint32_t depth_len, uint64_t *tile_range);
 // ord == nullptr: reads are coordinate-sorted; otherwise the tile ranges index `ord`.
 // ckpt: reference offset of the owning read at every CKPT_WORDS-word CIGAR boundary (written by launch_cigar_scan).
+size_t depth_items_bytes(uint32_t depth_len);
 void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *ref_end, const uint32_t *ckpt,
-                        uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range);
+                        uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range, uint32_t cigar_pad_words = 0,
+                        void *items = nullptr);
 // reference-offset checkpoints every CKPT_WORDS CIGAR words (scan.hip writes them, depth.hip starts its walks from them)
 constexpr int CKPT_SHIFT = 6, CKPT_WORDS = 1 << CKPT_SHIFT;
 static inline size_t ckpt_bytes(uint64_t n_cigar) { return ((n_cigar >> CKPT_SHIFT) + 2) * sizeof(uint32_t); }

@@ -280,7 +280,7 @@ static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, u
 // depth chain on device arrays. pmax / ord / range scratch comes from `a`; `ranges` != nullptr: the scan already produced the
 // tiles' candidate ranges (coordinate-sorted shard) and only the tile kernel remains.
 static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t *ref_end, const uint32_t *ckpt, bool unsorted, uint32_t depth_len,
-                       uint32_t *depth, ScanCounters *cnt, const uint64_t *ranges = nullptr)
+                       uint32_t *depth, ScanCounters *cnt, const uint64_t *ranges = nullptr, uint32_t cigar_pad = 0, void *items = nullptr)
 {
     const uint64_t n = d.n_reads;
     TimerScope ts(ctx, CSV_K_DEPTH);
@@ -289,7 +289,7 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
         return CSV_OK;
     }
     if (ranges && !unsorted) {
-        launch_depth_tiles(ctx->stream, d, nullptr, ref_end, ckpt, depth_len, depth, cnt, ranges);
+        launch_depth_tiles(ctx->stream, d, nullptr, ref_end, ckpt, depth_len, depth, cnt, ranges, cigar_pad, items);
         return CSV_OK;
     }
     int32_t *pmax = (int32_t *)arena_alloc(a, n * 4);
@@ -313,7 +313,7 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
     }
     launch_prefix_max(ctx->stream, end_s, pmax, n, ptmp);
     launch_depth_ranges(ctx->stream, pos_s, pmax, n, depth_len, ttmp);
-    launch_depth_tiles(ctx->stream, d, ord, ref_end, ckpt, depth_len, depth, cnt, ttmp);
+    launch_depth_tiles(ctx->stream, d, ord, ref_end, ckpt, depth_len, depth, cnt, ttmp, cigar_pad, items);
     return CSV_OK;
 }
 static size_t depth_chain_bytes(uint64_t n, uint32_t depth_len = 0xffffffffu)
@@ -798,6 +798,7 @@ static void shard_release(csv_shard *sh)
     }
     (void)hipFree(sh->ref_end); (void)hipFree(sh->q_start); (void)hipFree(sh->q_end);
     (void)hipFree(sh->ckpt);
+    (void)hipFree(sh->depth_items);
     (void)hipFree(sh->qhash);
     (void)hipFree(sh->depth); (void)hipFree(sh->sig_raw); (void)hipFree(sh->scratch); (void)hipFree(sh->counters);
     delete sh;
@@ -815,6 +816,7 @@ static csv_shard *shard_common(csv_ctx *ctx, csv_shard *sh)
     ok &= hipMalloc((void **)&sh->counters, sh->counters_bytes) == hipSuccess;
     sh->tile_range = (uint64_t *)((char *)sh->counters + align_up(kCntBytes, 256));
     ok &= hipMalloc((void **)&sh->ckpt, ckpt_bytes(sh->d.n_cigar)) == hipSuccess;
+    ok &= hipMalloc(&sh->depth_items, depth_items_bytes(sh->depth_len) + 16) == hipSuccess;
     sh->sig_cap = std::max<uint64_t>(1u << 18, n * 2);
     ok &= hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); ctx->err = "hipMalloc failed (shard)"; shard_release(sh); return nullptr; }
@@ -835,8 +837,9 @@ csv_shard *csvgpu_shard_upload(csv_ctx *ctx, const csv_reads *r, uint32_t depth_
     ok &= hipMalloc((void **)&sh->d.flag, n * 2 + 16) == hipSuccess;
     ok &= hipMalloc((void **)&sh->d.mapq, n + 16) == hipSuccess;
     ok &= hipMalloc((void **)&sh->d.cigar_off, (n + 1) * 8) == hipSuccess;
-    ok &= hipMalloc((void **)&sh->d.cigar, m * 4 + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->d.cigar, (m + CIGAR_PAD_WORDS) * 4) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); ctx->err = "hipMalloc failed (shard upload)"; shard_release(sh); return nullptr; }
+    sh->cigar_pad = CIGAR_PAD_WORDS;
     hipStream_t s = ctx->stream;
     sh->unsorted = 0;                                    // known before the first scan: lets the pipeline queue the depth pass without waiting
     for (uint64_t i = 1; i < n; i++) if (r->pos[i] < r->pos[i - 1]) { sh->unsorted = 1; break; }
@@ -848,6 +851,7 @@ csv_shard *csvgpu_shard_upload(csv_ctx *ctx, const csv_reads *r, uint32_t depth_
     }
     cp &= hipMemcpyAsync((void *)sh->d.cigar_off, r->cigar_off, (n + 1) * 8, hipMemcpyHostToDevice, s) == hipSuccess;
     if (m) cp &= hipMemcpyAsync((void *)sh->d.cigar, r->cigar, m * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+    cp &= hipMemsetAsync((void *)(sh->d.cigar + m), 0, (size_t)CIGAR_PAD_WORDS * 4, s) == hipSuccess;
     cp &= hipStreamSynchronize(s) == hipSuccess;
     if (!cp) { ctx->err = "H2D copy failed (shard upload)"; shard_release(sh); return nullptr; }
     return shard_common(ctx, sh);
@@ -1387,11 +1391,11 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
         CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, cs));
         CSV_HIP(ctx, hipEventRecord(job->ev_mid, cs));
         if (big != s) {                       // (timed through the pair's events, or not at all)
-            launch_depth_tiles(big, sh->d, nullptr, sh->ref_end, sh->ckpt, sh->depth_len, sh->depth, cnt, sh->tile_range);
+            launch_depth_tiles(big, sh->d, nullptr, sh->ref_end, sh->ckpt, sh->depth_len, sh->depth, cnt, sh->tile_range, sh->cigar_pad, sh->depth_items);
         } else {
             ctx->work.used = 0;
             if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt,
-                                  sorted ? sh->tile_range : nullptr))) return rc;
+                                  sorted ? sh->tile_range : nullptr, sh->cigar_pad, sh->depth_items))) return rc;
         }
         job->depth_queued = true;
         if (big != s) {
@@ -1496,7 +1500,7 @@ int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host
     // depth map + mean coverage + min_pts (device scalar), unless already queued behind the scan
     if (!job->depth_queued) {
         ctx->work.used = 0;
-        if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt))) return rc;
+        if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt, nullptr, sh->cigar_pad, sh->depth_items))) return rc;
         launch_min_pts(s, cnt, job->min_pts_pct);
     }
 

@@ -43,6 +43,14 @@ __device__ __forceinline__ uint32_t wave_total_dpp(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum_dpp(v), 63);
 }
 
+// clamp x to [0, hi] (hi >= 0, wave-uniform) in one instruction; hipcc only forms v_med3 from min(max()) when it can prove 0 <= hi
+__device__ __forceinline__ int32_t clamp0_i32(int32_t x, int32_t hi)
+{
+    int32_t r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+
 __device__ __forceinline__ int32_t wave_incl_max(int32_t v)
 {
     const int l = lane_id();

@@ -32,7 +32,8 @@ constexpr int DEPTH_WAVES = DEPTH_THREADS / WAVE;          // 8
 constexpr int DEPTH_PER_WAVE = DEPTH_TILE / DEPTH_WAVES;   // entries scanned per wave
 constexpr int DEPTH_ROUNDS = DEPTH_PER_WAVE / (4 * WAVE);  // rounds of 256 entries
 constexpr int WL_CAP = 512;                                // work-list items staged per batch (12 KiB of LDS)
-constexpr int DEPTH_PF = 3;                                // a walk keeps DEPTH_PF + 1 chunks in flight ahead of the one being worked on (1 -> 4: -4 %)
+constexpr int WL_SPEC = 256;                               // list entries a tile requests before it knows how many it has
+constexpr int DEPTH_PF = 5;                                // a walk keeps DEPTH_PF + 1 chunks in flight ahead of the one being worked on (1 -> 4: -4 %)
 
 // ------------------------------------------------------------------------------- prefix max
 constexpr int PM_THREADS = 256;
@@ -175,23 +176,158 @@ __global__ __launch_bounds__(256) void depth_ranges_kernel(const int32_t *__rest
     if (lane == 0) { tile_range[2 * (uint64_t)t] = ~lo; tile_range[2 * (uint64_t)t + 1] = hi; }      // encoding: common.hpp
 }
 
+// One (tile, candidate read) pair -> the walk item of the tile's work list, or nothing. Drops reads that end left of the tile or fail
+// the depth filter (cnv_caller.cpp:491-495), and searches the read's checkpoints (scan.hip records the read's reference offset at every
+// 64-word CIGAR boundary) for the last boundary left of the tile AND for the first one at or right of the tile's right edge: where the
+// walk starts and how many 1 KiB chunks it needs. Everything a candidate needs first is requested together (one round trip), the
+// checkpoint probes are the second; NP probes per search (more close more brackets in that trip, and cost registers).
+struct DepthItem {
+    uint32_t b0;        // the walk's first word / CKPT_WORDS (a checkpoint boundary)
+    uint32_t nrem;      // words from there to the end of what the walk needs (the read's end, or the first boundary right of the tile)
+    uint32_t pack;      // chunks to walk << 6 | first valid word, relative to the first (< 64)
+    int32_t  start;     // reference position of the first word, relative to the tile
+};
+template <int NP>
+__device__ __forceinline__ bool depth_make_item(uint64_t r, uint64_t T0, uint64_t T1, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
+                                                const uint64_t *__restrict__ cigar_off, const int32_t *__restrict__ ref_end,
+                                                const uint32_t *__restrict__ ckpt, DepthItem &out)
+{
+    const uint64_t c0 = cigar_off[r], c1 = cigar_off[r + 1];
+    const uint32_t fl = flag[r];
+    const int32_t r_end = ref_end[r], r_pos = pos[r];
+    if (!(((int64_t)r_end >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && c1 > c0)) return false;
+    const uint64_t p1 = (uint64_t)(uint32_t)((uint32_t)r_pos + 1u);     // 1-based first reference position, in uint32 as there (:498): pos -1 wraps to 0
+    // the read's boundaries are ckr[1 .. nb] (32-bit indices: a read has fewer than 2^25 of them)
+    const uint64_t g0 = c0 >> CKPT_SHIFT;
+    const uint32_t nb = (uint32_t)(((c1 - 1) >> CKPT_SHIFT) - g0);
+    const uint32_t *__restrict__ const ckr = ckpt + g0;
+    // f(x) = (p1 + ckr[x] <= X) is true up to the answer and false from it on; two such searches over x in [1, nb]:
+    // X = T0 -> `lo`, the first boundary NOT left of the tile (the walk starts at lo - 1), and X = T1 - 1 -> `e_lo`, the
+    // first boundary at or right of the tile's right edge (the walk needs no chunk that starts there).
+    uint32_t lo = 1, hi = nb + 1, e_lo = 1, e_hi = nb + 1;
+    uint32_t lo_val = 0;                                                 // ckr[lo - 1] whenever lo has moved
+    const uint64_t X1 = T1 - 1;
+    const bool want0 = nb > 0 && p1 <= T0;
+    const bool want1 = nb > 0 && p1 <= X1 && (int64_t)r_end >= (int64_t)T1;      // (a read that ends inside the tile needs all its chunks)
+    // The reference offset grows almost linearly with the word index, so each boundary is guessed by interpolation and NP
+    // independent probes around the guess usually close the bracket: one round trip (for both searches together) where a
+    // bisection of the read's ~20 checkpoints is five dependent ones. f is monotone, so the probes that satisfy it are a prefix of them.
+    const uint32_t rlen = (uint32_t)r_end - (uint32_t)p1 + 1u;          // (r_end >= T0 >= p1 wherever the guess is used)
+    const float per_pos = (float)nb / (float)(rlen ? rlen : 1u);
+    uint32_t v0[NP], v1[NP];
+    uint32_t gs0 = 0, gs1 = 0;
+    auto probe_at = [&](uint32_t guess, int i) { return min(max(guess + (uint32_t)i, (uint32_t)(1 + (NP / 2 - 1))) - (uint32_t)(NP / 2 - 1), nb); };
+    if (want0) {
+        gs0 = min(max(1u + (uint32_t)((float)(uint32_t)(T0 - p1) * per_pos), 1u), nb);
+#pragma unroll
+        for (int i = 0; i < NP; i++) v0[i] = ckr[probe_at(gs0, i)];
+    }
+    if (want1) {
+        gs1 = min(max(1u + (uint32_t)((float)(uint32_t)(X1 - p1) * per_pos), 1u), nb);
+#pragma unroll
+        for (int i = 0; i < NP; i++) v1[i] = ckr[probe_at(gs1, i)];
+    }
+    if (want0) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const uint32_t q = probe_at(gs0, i);
+            if (p1 + v0[i] <= T0) { lo = q + 1; lo_val = v0[i]; }
+            else hi = min(hi, q);
+        }
+    }
+    if (want1) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const uint32_t q = probe_at(gs1, i);
+            if (p1 + v1[i] <= X1) e_lo = q + 1;
+            else e_hi = min(e_hi, q);
+        }
+    } else e_lo = e_hi = (p1 <= X1 ? nb + 1 : 1u);
+    while (lo < hi || e_lo < e_hi) {                                     // both brackets shrink in the same round trips
+        const bool a0 = lo < hi, a1 = e_lo < e_hi;
+        const uint32_t mid = (lo + hi) >> 1, mie = (e_lo + e_hi) >> 1;
+        const uint32_t v = a0 ? ckr[mid] : 0u, u = a1 ? ckr[mie] : 0u;
+        if (a0) { if (p1 + v <= T0) { lo = mid + 1; lo_val = v; } else hi = mid; }
+        if (a1) { if (p1 + u <= X1) e_lo = mie + 1; else e_hi = mie; }
+    }
+    uint64_t chunk = c0 & ~(uint64_t)(CKPT_WORDS - 1); uint32_t carry = 0;     // walks start on a checkpoint: at most 63 words re-read
+    if (lo > 1) { chunk = (g0 + lo - 1) << CKPT_SHIFT; carry = lo_val; }
+    if (!(p1 + carry < T1)) return false;                                // the whole read lies right of the tile
+    // Words the walk needs: up to the read's end, or up to the first boundary at or right of the tile's right edge (e_lo, relative to
+    // g0 like b0) — the walk fetches and decodes nothing behind it, and the reference offset there is >= T1 by definition, so the span
+    // the walk accumulates still reaches the tile's edge.
+    const uint32_t b0 = lo > 1 ? lo - 1 : 0u;
+    uint32_t nrem = (uint32_t)(c1 - chunk);
+    if (e_lo <= nb) nrem = min(nrem, (e_lo - b0) << CKPT_SHIFT);
+    const uint32_t n_chunks = (nrem + 4 * WAVE - 1) / (4 * WAVE);
+    out.b0 = (uint32_t)(chunk >> CKPT_SHIFT);
+    out.nrem = nrem;
+    out.pack = (n_chunks << 6) | (uint32_t)(c0 > chunk ? c0 - chunk : 0);
+    out.start = (int32_t)((uint32_t)p1 - (uint32_t)T0 + carry);
+    return true;
+}
+
+// The work lists of all tiles, ahead of the tile kernel: one small workgroup per tile examines the tile's first WL_CAP candidates and
+// leaves their items in HBM (items[tile][..], n_items[tile]). Inside the tile kernel the same work costs a tile 30 % of its time — four
+// dependent round trips to HBM in front of the walk, every thread of the 1024 waiting for the slowest candidate, the tile's 64 KiB of
+// LDS idle meanwhile; here nothing waits for it: 8 workgroups per CU hide each other's round trips. (Later batches of a tile with
+// more than WL_CAP candidates — hundreds-fold coverage — are still built by the tile kernel itself.)
+constexpr int ITEMS_THREADS = 128;
+__global__ __launch_bounds__(ITEMS_THREADS) void depth_items_kernel(
+    const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ ord,
+    const int32_t *__restrict__ ref_end, const uint64_t *tile_range, const uint32_t *__restrict__ ckpt, uint32_t depth_len,
+    DepthItem *__restrict__ items, uint32_t *__restrict__ n_items)
+{
+    __shared__ unsigned int wl_n;
+    const uint64_t T0 = (uint64_t)blockIdx.x * DEPTH_TILE;
+    const uint64_t T1 = min(T0 + (uint64_t)DEPTH_TILE, (uint64_t)depth_len);
+    const uint64_t k_lo = ~tile_range[2 * (uint64_t)blockIdx.x];
+    const uint64_t k_hi = min(max(k_lo, (uint64_t)tile_range[2 * (uint64_t)blockIdx.x + 1]), k_lo + WL_CAP);
+    if (threadIdx.x == 0) wl_n = 0;
+    __syncthreads();
+    DepthItem *__restrict__ const mine = items + (uint64_t)blockIdx.x * WL_CAP;
+    for (uint64_t kk = k_lo + threadIdx.x; kk < k_hi; kk += ITEMS_THREADS) {
+        DepthItem it;
+        if (depth_make_item<8>(ord ? (uint64_t)ord[kk] : kk, T0, T1, pos, flag, cigar_off, ref_end, ckpt, it))
+            *reinterpret_cast<uint4 *>(&mine[atomicAdd(&wl_n, 1u)]) = *reinterpret_cast<const uint4 *>(&it);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) n_items[blockIdx.x] = wl_n;
+}
+
+#ifdef DEPTH_PHASE_PROBE
+__device__ unsigned long long g_depth_phase[8];
+extern "C" void csvgpu_debug_depth_phase(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_depth_phase), z, sizeof z); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_depth_phase), 64);
+}
+#define PHASE_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_depth_phase[i], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+// PADDED: the CIGAR array is 16-byte aligned and followed by at least 4 * WAVE allocated words (csvgpu_shard_upload's own arrays):
+// every chunk load is one unconditional 16-byte load per lane.
+template <bool PADDED>
 __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int vec_ok, int dvec_ok,
     const uint32_t *__restrict__ ord,        // nullptr: reads already sorted by pos; else the tile ranges index `ord`
     const int32_t *__restrict__ ref_end, const uint64_t *tile_range,        // (written by atomics of the previous kernel: no __restrict__ / read-only path)
     const uint32_t *__restrict__ ckpt,       // reference offset of the owning read at every CKPT_WORDS-word boundary (scan.hip)
-    uint32_t depth_len, uint32_t *__restrict__ depth, ScanCounters *__restrict__ cnt)
+    uint32_t depth_len, uint32_t *__restrict__ depth, ScanCounters *__restrict__ cnt,
+    const DepthItem *__restrict__ items, const uint32_t *__restrict__ n_items_pre)      // depth_items_kernel's lists, or null
 {
     __shared__ alignas(16) uint32_t diff[DEPTH_TILE + 4];
     __shared__ uint32_t wave_tot[DEPTH_WAVES];
     __shared__ unsigned long long blk_sum;
     __shared__ unsigned int blk_nz;
     __shared__ unsigned int next_item, wl_n;
-    __shared__ uint64_t wl_chunk[WL_CAP];
-    __shared__ int32_t wl_c0rel[WL_CAP];
-    __shared__ uint32_t wl_nrem[WL_CAP], wl_p1[WL_CAP], wl_carry[WL_CAP];
+    __shared__ alignas(16) DepthItem wl[WL_CAP];
 
+#ifdef DEPTH_PHASE_PROBE
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const uint64_t T0 = (uint64_t)blockIdx.x * DEPTH_TILE;
@@ -201,158 +337,161 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     // is in flight while the tile's difference array is zeroed; the first barrier of the batch loop below covers both
     const uint64_t k_lo = ~tile_range[2 * (uint64_t)blockIdx.x];
     const uint64_t k_hi = max(k_lo, (uint64_t)tile_range[2 * (uint64_t)blockIdx.x + 1]);
+    const uint32_t n_pre = items ? n_items_pre[blockIdx.x] : 0u;        // (scalar load, in flight with the zeroing like the range)
+    // the first WL_SPEC list entries are requested before their count is known (most tiles of a 30x shard have fewer): one round trip
+    // less in front of the walk
+    uint4 spec = make_uint4(0u, 0u, 0u, 0u);
+    if (items && threadIdx.x < WL_SPEC) spec = *reinterpret_cast<const uint4 *>(&items[(uint64_t)blockIdx.x * WL_CAP + threadIdx.x]);
     for (int i = threadIdx.x * 4; i < DEPTH_TILE + 4; i += DEPTH_THREADS * 4) *reinterpret_cast<uint4 *>(&diff[i]) = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x == 0) { blk_sum = 0; blk_nz = 0; }
 
-    // Work list: the candidates are examined ONCE per tile by all threads together — thread t takes candidate t of the
-    // batch, loads its metadata (coalesced across threads), drops reads that end left of the tile or fail the depth filter
-    // (cnv_caller.cpp:491-495), and searches the read's checkpoints for the last 64-word boundary left of the tile.
-    // Surviving (start chunk, reference carry, word range) items go to LDS; the waves then pull items from an LDS counter
+    // Work list: the tile's (start chunk, start position, word range, chunk count) items, from depth_items_kernel's list (first batch)
+    // or built here by all threads together — thread t takes candidate t of the batch; the waves then pull items from an LDS counter
     // and go straight to CIGAR chunk loads, with no per-read metadata or checkpoint latency on their critical path.
     for (uint64_t cb = k_lo; cb < k_hi; cb += WL_CAP) {
-        if (threadIdx.x == 0) { wl_n = 0; next_item = 0; }
+        if (threadIdx.x == 0) { wl_n = (items && cb == k_lo) ? n_pre : 0u; next_item = 0; }
         __syncthreads();
-        const uint64_t kk = cb + threadIdx.x;
-        if (threadIdx.x < WL_CAP && kk < k_hi) {
-            const uint64_t r = ord ? (uint64_t)ord[kk] : kk;
-            // everything a candidate needs first is requested together (one round trip), the checkpoint probes are the second, and the
-            // reference offset of the start boundary is the value the last successful probe returned: two dependent round trips per tile
-            const uint64_t c0 = cigar_off[r], c1 = cigar_off[r + 1];
-            const uint32_t fl = flag[r];
-            const int32_t r_end = ref_end[r], r_pos = pos[r];
-            const bool ok = ((int64_t)r_end >= (int64_t)T0) && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && c1 > c0;
-            if (ok) {
-                const uint64_t p1 = (uint64_t)(uint32_t)((uint32_t)r_pos + 1u);     // 1-based first reference position, in uint32 as there (:498): pos -1 wraps to 0
-                const uint64_t g0 = c0 >> CKPT_SHIFT, g1 = (c1 - 1) >> CKPT_SHIFT;
-                uint64_t lo = g0 + 1, hi = g1 + 1;                                   // first boundary NOT left of the tile
-                uint32_t lo_val = 0;                                                 // ckpt[lo - 1] whenever lo has moved
-                // The reference offset grows almost linearly with the word index, so the boundary is guessed by interpolation and
-                // three independent probes around the guess usually close the bracket: one round trip where a bisection of the
-                // read's ~20 checkpoints is five dependent ones (this search sits on every tile's critical path).
-                if (lo < hi && p1 <= T0) {
-                    const uint64_t rlen = (uint64_t)((int64_t)r_end - (int64_t)p1 + 1);
-                    uint64_t guess = lo + (uint64_t)((double)(T0 - p1) / (double)(rlen ? rlen : 1) * (double)(hi - lo));
-                    guess = min(max(guess, lo), hi - 1);
-                    const uint64_t ga = guess > lo ? guess - 1 : lo, gb = guess, gc = min(guess + 1, hi - 1);
-                    const uint32_t ka = ckpt[ga], kb = ckpt[gb], kc = ckpt[gc];
-                    // f(g) = (p1 + ckpt[g] <= T0) is true up to the answer and false from it on
-                    if (p1 + kc <= T0) { lo = gc + 1; lo_val = kc; }
-                    else {
-                        hi = gc;
-                        if (p1 + kb <= T0) { lo = gb + 1; lo_val = kb; }
-                        else { hi = gb; if (p1 + ka <= T0) { lo = ga + 1; lo_val = ka; } else hi = ga; }
-                    }
-                }
-                while (lo < hi) {
-                    const uint64_t mid = (lo + hi) >> 1;
-                    const uint32_t v = ckpt[mid];
-                    if (p1 + v <= T0) { lo = mid + 1; lo_val = v; } else hi = mid;
-                }
-                uint64_t chunk = c0 & ~(uint64_t)(CKPT_WORDS - 1); uint32_t carry = 0;     // walks start on a checkpoint: at most 63 words re-read
-                if (lo > g0 + 1) { chunk = (lo - 1) << CKPT_SHIFT; carry = lo_val; }
-                if (p1 + carry < T1) {                                               // else the whole read lies right of the tile
-                    const uint32_t slot = atomicAdd(&wl_n, 1u);
-                    wl_chunk[slot] = chunk;
-                    wl_c0rel[slot] = (int32_t)((int64_t)c0 - (int64_t)chunk);        // first valid word, relative to the start chunk
-                    wl_nrem[slot] = (uint32_t)(c1 - chunk);                          // words from the start chunk to the read's end
-                    wl_p1[slot] = (uint32_t)p1;
-                    wl_carry[slot] = carry;
-                }
+        PHASE_MARK(0);
+        if (items && cb == k_lo) {
+            if (threadIdx.x < WL_SPEC) *reinterpret_cast<uint4 *>(&wl[threadIdx.x]) = spec;
+            else if (threadIdx.x < n_pre)
+                *reinterpret_cast<uint4 *>(&wl[threadIdx.x]) = *reinterpret_cast<const uint4 *>(&items[(uint64_t)blockIdx.x * WL_CAP + threadIdx.x]);
+        } else {
+            const uint64_t kk = cb + threadIdx.x;
+            if (threadIdx.x < WL_CAP && kk < k_hi) {
+                DepthItem it;
+                if (depth_make_item<3>(ord ? (uint64_t)ord[kk] : kk, T0, T1, pos, flag, cigar_off, ref_end, ckpt, it))
+                    *reinterpret_cast<uint4 *>(&wl[atomicAdd(&wl_n, 1u)]) = *reinterpret_cast<const uint4 *>(&it);
             }
         }
         __syncthreads();
+        PHASE_MARK(1);
         const uint32_t n_items = wl_n;
         const int32_t TW = (int32_t)(T1 - T0);                                      // tile width in positions
-        // How many chunks does a walk need? A chunk boundary is a checkpoint slot, so the checkpoints say exactly where a read's
-        // chunks start on the reference: lane l looks up the start of chunk l + 1 of the item, one vector load — requested while the
-        // PREVIOUS item of this wave is being walked, so nobody waits for it. The walk then fetches no chunk that starts right of the
-        // tile's right edge (DEPTH_PF + 1 chunks are kept in flight — the walk is bound by the bytes its 32 waves per CU keep in
-        // flight more than by anything else —: without the count every (tile, read) pair fetched that many chunks past the edge).
-        auto look_ahead = [&](uint32_t item) -> uint32_t {
-            const uint32_t off = (uint32_t)(lane + 1) * (4 * WAVE);
-            return off < uniform32(wl_nrem[item]) ? ckpt[(uniform64(wl_chunk[item]) + off) >> CKPT_SHIFT] : 0xffffffffu;
-        };
-        uint32_t it = depth_grab(&next_item, lane);
-        uint32_t la = it < n_items ? look_ahead(it) : 0u;
-        while (it < n_items) {
-            const uint64_t chunk0 = uniform64(wl_chunk[it]);                        // `it` is wave-uniform: keep the item in scalar registers
-            const int32_t c0rel = (int32_t)uniform32((uint32_t)wl_c0rel[it]);
-            const uint32_t nrem = uniform32(wl_nrem[it]);
-            // Positions are kept relative to the tile's left edge in 32-bit signed arithmetic (coordinates and run lengths are
-            // below 2^31, the BAM limit): a run [rel, rel + len) clips to [max(rel,0), min(rel+len, TW)) with one max and one min,
-            // and a run with no aligned bases (len masked to 0) clips to nothing, so no separate op test is needed.
-            const int32_t p1rel = (int32_t)uniform32(wl_p1[it] - (uint32_t)T0);     // the read's first position, relative to the tile
-            int32_t base_rel = p1rel + (int32_t)uniform32(wl_carry[it]);            // wave-uniform: position of the chunk's first staged word
-            const uint32_t it_next = depth_grab(&next_item, lane);
-            auto load_chunk = [&](uint32_t off, uint32_t (&dst)[4]) {
-                const uint64_t c = chunk0 + off;
-                if (vec_ok && c + 4 * WAVE <= n_cigar) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(cigar + c + (uint64_t)lane * 4); dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-                } else depth_load4(cigar, n_cigar, vec_ok, c + (uint64_t)lane * 4, dst);
-            };
-            uint32_t la_next = 0u;
-            {
-                uint32_t n_chunks = (nrem + 4 * WAVE - 1) / (4 * WAVE);
-                {   // chunks after the first that start left of the right edge: a prefix of the lanes (reference offsets do not decrease).
-                    // All 64 looked-up chunks needed: the walk is longer than the look-up reaches and runs to the read's end as before.
-                    const uint32_t n_more = (uint32_t)__popcll(__ballot(la != 0xffffffffu && p1rel + (int32_t)la < TW));
-                    if (n_more < (uint32_t)WAVE) n_chunks = min(n_chunks, n_more + 1u);
+        // Positions are kept relative to the tile's left edge in 32-bit signed arithmetic (coordinates and run lengths are below 2^31, the
+        // BAM limit).
+        //
+        // The walk. A (tile, read) item is short — three or four chunks on a 30x ONT shard, one on HiFi — so a wave that fetched an item's
+        // chunks when it reached the item spent most of its time waiting for that first round trip (the kernel was bound by latency, not
+        // by instructions: halving its LDS atomics changed nothing). The wave's items are therefore ONE stream of chunks: a fetch cursor
+        // runs DEPTH_PF + 1 chunks ahead of the chunk being worked on, straight across item boundaries, into a ring of chunk buffers with
+        // STATIC indices (the loop is unrolled by the ring's size; a buffer is refilled in place the moment its words have been decoded).
+        // Every step issues exactly one load (a repeat of the last address once the stream has run dry), so the compiler's vmcnt counts
+        // stay exact. What the consumer needs to know about a buffer's chunk travels in scalar registers next to it.
+        if (n_items) {
+            uint32_t w[DEPTH_PF + 1][4];
+            uint32_t m_o0[DEPTH_PF + 1], m_nrem[DEPTH_PF + 1], m_c0rel[DEPTH_PF + 1];
+            int32_t m_start[DEPTH_PF + 1];
+            bool m_valid[DEPTH_PF + 1], m_first[DEPTH_PF + 1];
+            uint64_t f_chunk0 = 0, f_addr = 0;
+            uint32_t f_n = 0, f_c = 0, f_nrem = 0, f_c0rel = 0, f_off = 0;
+            int32_t f_start = 0;
+            bool f_done = false;
+            uint32_t nxt_v = 0;                                                     // lane 0: the next item's index (an LDS atomic in flight)
+            if (lane == 0) nxt_v = atomicAdd(&next_item, 1u);
+            auto fetch = [&](int j) {
+                if (f_c == f_n && !f_done) {
+                    const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_v);
+                    if (it < n_items) {
+                        const uint4 d = *reinterpret_cast<const uint4 *>(&wl[it]);      // {b0, nrem, pack, start}
+                        f_chunk0 = (uint64_t)uniform32(d.x) << CKPT_SHIFT;
+                        f_nrem = uniform32(d.y);
+                        f_start = (int32_t)uniform32(d.w);
+                        const uint32_t pk = uniform32(d.z);
+                        f_n = pk >> 6; f_c0rel = pk & 63u; f_c = 0;
+                        if (lane == 0) nxt_v = atomicAdd(&next_item, 1u);
+                    } else f_done = true;
                 }
-                // DEPTH_PF + 1 chunk buffers used as a ring with STATIC indices: the chunk loop is unrolled by the ring's size, so a buffer
-                // is refilled in place the moment its words have been decoded (rotating the buffers cost 12 register moves per chunk,
-                // a sixth of the loop's vector instructions).
-                uint32_t w[DEPTH_PF + 1][4];
+                m_valid[j] = !f_done;
+                if (!f_done) {
+                    m_o0[j] = f_c * (4 * WAVE); m_nrem[j] = f_nrem; m_c0rel[j] = f_c0rel; m_start[j] = f_start; m_first[j] = f_c == 0;
+                    f_off = f_c * (4 * WAVE);
+                    f_addr = f_chunk0 + (uint64_t)f_off;
+                    f_c++;
+                }
+                if (PADDED) {
+                    // lanes whose four words all lie behind the item's last word repeat the last lane that has one: no cache line is fetched
+                    // for them, and the load stays unconditional (the consumer masks those words anyway)
+                    const uint32_t lw = min((uint32_t)lane * 4, (f_nrem - 1u - f_off) & ~3u);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(cigar + f_addr + lw);
+                    w[j][0] = v.x; w[j][1] = v.y; w[j][2] = v.z; w[j][3] = v.w;
+                } else if (vec_ok && f_addr + 4 * WAVE <= n_cigar) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(cigar + f_addr + (uint64_t)lane * 4);
+                    w[j][0] = v.x; w[j][1] = v.y; w[j][2] = v.z; w[j][3] = v.w;
+                } else depth_load4(cigar, n_cigar, vec_ok, f_addr + (uint64_t)lane * 4, w[j]);
+            };
+#pragma unroll
+            for (int j = 0; j <= DEPTH_PF; j++) fetch(j);
+            int32_t base_rel = 0;                                                    // wave-uniform: position of the chunk's first word
+            bool walking = true;
+            while (walking) {
 #pragma unroll
                 for (int j = 0; j <= DEPTH_PF; j++) {
+                    if (!walking) break;
+                    if (!m_valid[j]) { walking = false; break; }                    // the stream has run dry (buffers are consumed in fetch order)
+                    const uint32_t o0 = m_o0[j], nrem = m_nrem[j], c0rel = m_c0rel[j];      // word offset of this chunk from the item's first chunk
+                    if (m_first[j]) base_rel = m_start[j];
+                    uint32_t (&cur)[4] = w[j];
+                    // only the first and the last chunk of an item can hold words of a neighbouring read
+                    if (!(o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
+                        const uint32_t o = o0 + (uint32_t)lane * 4;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) w[j][k] = 0;
-                    if ((uint32_t)j < n_chunks) load_chunk((uint32_t)j * (4 * WAVE), w[j]);
-                }
-                if (it_next < n_items) la_next = look_ahead(it_next);                // in flight during this walk
-                bool walking = true;
-                for (uint32_t c0 = 0; walking; c0 += DEPTH_PF + 1) {
-#pragma unroll
-                    for (int j = 0; j <= DEPTH_PF; j++) {
-                        if (!walking) break;
-                        const uint32_t c = c0 + (uint32_t)j;
-                        const uint32_t o0 = c * (4 * WAVE);                         // word offset of this chunk from chunk0
-                        uint32_t (&cur)[4] = w[j];
-                        // only the first and the last chunk of an item can hold words of a neighbouring read
-                        if (!((int32_t)o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
-                            const int32_t o = (int32_t)o0 + lane * 4;
-#pragma unroll
-                            for (int k = 0; k < 4; k++) if (!((o + k >= c0rel) && ((uint32_t)(o + k) < nrem))) cur[k] = (uint32_t)OP_P;
-                        }
-                        uint32_t rl[4], al[4], lane_ref = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            // v_bfe_i32 takes its bit offset from the word's low five bits (op + the length's lowest bit): op masks repeated at bit 16
-                            const uint32_t len = cur[k] >> 4;
-                            rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), cur[k], 1u);    // all-ones when the op consumes the reference
-                            al[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(ALN_OPS | (ALN_OPS << 16)), cur[k], 1u);    // ... when its bases count toward depth
-                            lane_ref += rl[k];
-                        }
-                        // the buffer's words are decoded: refill it with the chunk DEPTH_PF + 1 ahead
-                        if (c + DEPTH_PF + 1 < n_chunks) load_chunk(o0 + (DEPTH_PF + 1) * (4 * WAVE), w[j]);
-                        const uint32_t incl = wave_incl_sum_dpp(lane_ref);
-                        int32_t rel = base_rel + (int32_t)(incl - lane_ref);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int32_t a = max(rel, 0), b = min(rel + (int32_t)al[k], TW);   // T1 <= depth_len: out-of-range bases dropped (:511-515)
-                            if (a < b) {
-                                atomicAdd(&diff[a], 1u);
-                                atomicAdd(&diff[b], 0xffffffffu);
-                            }
-                            rel += (int32_t)rl[k];
-                        }
-                        base_rel += (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                        if (c + 1 >= n_chunks || base_rel >= TW) walking = false;   // the read ends here, or the rest of it lies right of the tile
+                        for (int k = 0; k < 4; k++) if (!((o + k >= c0rel) && (o + k < nrem))) cur[k] = (uint32_t)OP_P;
                     }
+                    // depth = (reads whose reference span covers the position) - (their D / N gaps over it): the same number as counting the
+                    // aligned bases of every M / = / X run (cnv_caller.cpp:498-520), with HALF the difference-array updates on an ONT CIGAR
+                    // (a gap op is every fourth op, an aligned run every second) and none of the run-end arithmetic: a gap covers
+                    // [cursor before it, cursor after it), so its two updates sit at cursor values the walk computes anyway.
+                    uint32_t rl[4], gp[4], lane_ref = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        // v_bfe_i32 takes its bit offset from the word's low five bits (op + the length's lowest bit): op masks repeated at bit 16
+                        const uint32_t len = cur[k] >> 4;
+                        rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), cur[k], 1u);    // all-ones when the op consumes the reference
+                        gp[k] = (uint32_t)__builtin_amdgcn_sbfe((int)(GAP_OPS | (GAP_OPS << 16)), cur[k], 1u);          // ... when it does so without aligned bases
+                        lane_ref += rl[k];
+                    }
+                    fetch(j);                                                       // the buffer's words are decoded: refill it
+                    const uint32_t incl = wave_incl_sum_dpp(lane_ref);
+                    const int32_t total = (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    const int32_t rel0 = base_rel + (int32_t)(incl - lane_ref);
+                    {   // the chunk's share of the read's span, clipped to the tile (T1 <= depth_len: out-of-range bases dropped, :511-515);
+                        // consecutive chunks cancel at their common boundary
+                        const int32_t sa = min(max(base_rel, 0), TW), sb = min(max(base_rel + total, 0), TW);
+                        if (sa != sb && lane < 2) atomicAdd(&diff[lane ? sb : sa], lane ? 0xffffffffu : 1u);
+                    }
+                    if (base_rel >= 0 && base_rel + total <= TW) {
+                        // the whole chunk lies inside the tile (most do: a tile is seven chunks wide): cursors as byte offsets, no clipping
+                        uint32_t a4 = (uint32_t)rel0 << 2;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t n4 = (rl[k] << 2) + a4;
+                            if (gp[k]) {
+                                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(diff) + a4), 0xffffffffu);
+                                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(diff) + n4), 1u);
+                            }
+                            a4 = n4;
+                        }
+                    } else {
+                        int32_t rel = rel0, a = clamp0_i32(rel0, TW);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            rel += (int32_t)rl[k];
+                            const int32_t b = clamp0_i32(rel, TW);
+                            if (gp[k]) {                                       // (both ends clipped to the same edge cancel)
+                                atomicAdd(&diff[a], 0xffffffffu);
+                                atomicAdd(&diff[b], 1u);
+                            }
+                            a = b;
+                        }
+                    }
+                    base_rel += total;
                 }
             }
-            it = it_next; la = la_next;
         }
+        PHASE_MARK(2);
         __syncthreads();
+        PHASE_MARK(3);
     }
 
     if (k_lo >= k_hi) __syncthreads();       // no batch ran (empty tile): the zeroing above has not met a barrier yet
@@ -402,6 +541,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     my_nz = wave_sum(my_nz);
     if (lane == 0) { atomicAdd(&blk_sum, (unsigned long long)my_sum); atomicAdd(&blk_nz, my_nz); }
     __syncthreads();
+    PHASE_MARK(4);
     if (threadIdx.x == 0) {
         if (blk_sum) atomicAdd(&cnt->depth_sum, blk_sum);
         if (blk_nz) atomicAdd(&cnt->depth_nonzero, blk_nz);
@@ -417,15 +557,27 @@ void launch_depth_ranges(hipStream_t s, const int32_t *pos_s, const int32_t *pma
     hipLaunchKernelGGL(depth_ranges_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, pos_s, pmax_end, n_reads, depth_len, tiles, tile_range);
 }
 
+// items: depth_items_bytes(depth_len) bytes of scratch (work lists of all tiles, built by a kernel of its own ahead of the tile kernel), or
+// null: every tile builds its own list
+size_t depth_items_bytes(uint32_t depth_len) { return align_up((size_t)depth_n_tiles(depth_len) * (WL_CAP * sizeof(DepthItem) + sizeof(uint32_t)), 256); }
+
 void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *ref_end, const uint32_t *ckpt,
-                        uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range)
+                        uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range, uint32_t cigar_pad_words, void *items)
 {
     if (depth_len == 0) return;
     const unsigned tiles = depth_n_tiles(depth_len);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     const int dvec_ok = (((uintptr_t)depth) & 15u) == 0;
-    hipLaunchKernelGGL(depth_tile_kernel, dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
-                       d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt);
+    DepthItem *it = (DepthItem *)items;
+    uint32_t *n_it = items ? (uint32_t *)(it + (size_t)tiles * WL_CAP) : nullptr;
+    if (items)
+        hipLaunchKernelGGL(depth_items_kernel, dim3(tiles), dim3(ITEMS_THREADS), 0, s, d.pos, d.flag, d.cigar_off, ord, ref_end, tile_range, ckpt, depth_len, it, n_it);
+    if (vec_ok && cigar_pad_words >= 4 * WAVE)
+        hipLaunchKernelGGL(depth_tile_kernel<true>, dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
+                           d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt, it, n_it);
+    else
+        hipLaunchKernelGGL(depth_tile_kernel<false>, dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
+                           d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt, it, n_it);
 }
 
 // min_pts = (int)ceil(mean_cov * pct), or 5 when pct <= 0 (sv_caller.cpp:723-728); mean = sum / #non-zero

@@ -65,7 +65,11 @@ __device__ __forceinline__ void ring_issue(uint32_t *slot, const uint32_t *__res
 // fills ago has landed (stores in between only make the wait more conservative).
 __device__ __forceinline__ void ring_wait_steady()
 {
-    static_assert(RING_D >= 2 && RING_D <= 4, "add the immediate for RING_D - 1");
+    static_assert(RING_D >= 2 && RING_D <= 8, "add the immediate for RING_D - 1");
+    if (RING_D == 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if (RING_D == 7) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (RING_D == 6) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if (RING_D == 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (RING_D == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     if (RING_D == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if (RING_D == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
