@@ -43,6 +43,14 @@ __device__ __forceinline__ uint32_t wave_total_dpp(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum_dpp(v), 63);
 }
 
+// (a << 2) + b in one instruction (hipcc reassociates the C expression into an add and a shift when b is itself such a sum)
+__device__ __forceinline__ uint32_t lshl2_add(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // clamp x to [0, hi] (hi >= 0, wave-uniform) in one instruction; hipcc only forms v_med3 from min(max()) when it can prove 0 <= hi
 __device__ __forceinline__ int32_t clamp0_i32(int32_t x, int32_t hi)
 {

@@ -434,9 +434,9 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                     uint32_t (&cur)[4] = w[j];
                     // only the first and the last chunk of an item can hold words of a neighbouring read
                     if (!(o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
-                        const uint32_t o = o0 + (uint32_t)lane * 4;
+                        const uint32_t t = o0 + (uint32_t)lane * 4 - c0rel, lim = nrem - c0rel;      // word o is the item's iff o - c0rel < nrem - c0rel (unsigned)
 #pragma unroll
-                        for (int k = 0; k < 4; k++) if (!((o + k >= c0rel) && (o + k < nrem))) cur[k] = (uint32_t)OP_P;
+                        for (int k = 0; k < 4; k++) if (!(t + k < lim)) cur[k] = (uint32_t)OP_P;
                     }
                     // depth = (reads whose reference span covers the position) - (their D / N gaps over it): the same number as counting the
                     // aligned bases of every M / = / X run (cnv_caller.cpp:498-520), with HALF the difference-array updates on an ONT CIGAR
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                         uint32_t a4 = (uint32_t)rel0 << 2;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const uint32_t n4 = (rl[k] << 2) + a4;
+                            const uint32_t n4 = lshl2_add(rl[k], a4);
                             if (gp[k]) {
                                 atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(diff) + a4), 0xffffffffu);
                                 atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(diff) + n4), 1u);
