@@ -90,6 +90,7 @@ struct csv_shard {
     char     *scratch = nullptr;   size_t scratch_cap = 0;   // sort / dbscan workspace
     uint64_t *counters = nullptr;  // device scalars (see ScanCounters) + bucket tables + the depth tiles' candidate ranges, zeroed together per chromosome
     uint64_t *tile_range = nullptr;   // inside `counters`
+    uint64_t *scan_split = nullptr;   // the scan's work split for this device's grid (launch_scan_split, once per shard)
     void     *depth_items = nullptr;  // depth_items_bytes(depth_len): the depth tiles' work lists (depth.hip)
     uint64_t *qhash = nullptr;        // [n_reads] std::hash<std::string> of every record's query name (csvgpu_shard_set_qname_hash), or null
     size_t    counters_bytes = 0;
@@ -158,7 +159,10 @@ struct ScanExtras {
 };
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
-                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &extras = ScanExtras());
+                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &extras = ScanExtras(),
+                       const uint64_t *split = nullptr /* launch_scan_split's table for the same n_cu and shard */);
+size_t scan_split_bytes(int n_cu, uint64_t n_reads);
+void launch_scan_split(hipStream_t s, int n_cu, const csv_reads &d, uint64_t *split);      // once per resident shard
 void launch_validate_offsets(hipStream_t s, const uint64_t *cigar_off, uint64_t n_reads, uint64_t n_cigar, uint64_t max_words, uint32_t *bad /* zeroed; set to 1 */);
 uint32_t scan_start_limit(uint32_t depth_len);   // exclusive bound on signature starts that the ordering keys are sized for
 // depth.hip

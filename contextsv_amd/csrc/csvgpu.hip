@@ -799,6 +799,7 @@ static void shard_release(csv_shard *sh)
     (void)hipFree(sh->ref_end); (void)hipFree(sh->q_start); (void)hipFree(sh->q_end);
     (void)hipFree(sh->ckpt);
     (void)hipFree(sh->depth_items);
+    (void)hipFree(sh->scan_split);
     (void)hipFree(sh->qhash);
     (void)hipFree(sh->depth); (void)hipFree(sh->sig_raw); (void)hipFree(sh->scratch); (void)hipFree(sh->counters);
     delete sh;
@@ -817,9 +818,13 @@ static csv_shard *shard_common(csv_ctx *ctx, csv_shard *sh)
     sh->tile_range = (uint64_t *)((char *)sh->counters + align_up(kCntBytes, 256));
     ok &= hipMalloc((void **)&sh->ckpt, ckpt_bytes(sh->d.n_cigar)) == hipSuccess;
     ok &= hipMalloc(&sh->depth_items, depth_items_bytes(sh->depth_len) + 16) == hipSuccess;
+    ok &= hipMalloc((void **)&sh->scan_split, scan_split_bytes(ctx->n_cu, sh->d.n_reads) + 16) == hipSuccess;
     sh->sig_cap = std::max<uint64_t>(1u << 18, n * 2);
     ok &= hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); ctx->err = "hipMalloc failed (shard)"; shard_release(sh); return nullptr; }
+    // the scan's work split for this device's grid, once per shard (the offsets are on the device by now)
+    launch_scan_split(ctx->stream, ctx->n_cu, sh->d, sh->scan_split);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "scan split failed (shard)"; shard_release(sh); return nullptr; }
     return sh;
 }
 
@@ -1367,14 +1372,14 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
         t0 = get_event(ctx);
         if (t0) CSV_HIP(ctx, hipEventRecord(t0, big));
         launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range));
+                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range), sh->scan_split);
     } else if (big != s) {                  // on the gate's stream, not a timed pair: no events of its own
         launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range));
+                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range), sh->scan_split);
     } else {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN, big);
         launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sorted ? sh->tile_range : nullptr));
+                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sorted ? sh->tile_range : nullptr), sh->scan_split);
     }
     job->depth_queued = false;
     if (sh->unsorted >= 0) {

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     int vec_ok, uint32_t depth_len, uint32_t start_limit, uint32_t min_oplen, uint32_t min_mapq, int emit,
     csv_sig *__restrict__ sig_out, uint64_t sig_cap, int32_t *__restrict__ ref_end, int32_t *__restrict__ q_start,
     int32_t *__restrict__ q_end, uint32_t *__restrict__ ckpt, ScanCounters *__restrict__ cnt,
-    unsigned long long *__restrict__ tile_range, uint32_t n_tiles, uint32_t *__restrict__ bucket_hist, int hist_type_pos, int hist_shift)
+    unsigned long long *__restrict__ tile_range, uint32_t n_tiles, uint32_t *__restrict__ bucket_hist, int hist_type_pos, int hist_shift,
+    const uint64_t *__restrict__ split)      // scan_split_kernel's table for this grid (resident shards: first read and its first word per wave), or null
 {
     __shared__ csv_sig buf[SIG_BUF];
     __shared__ alignas(16) uint32_t ring[SCAN_WAVES][RING_D][CHUNK_WORDS];      // 16-byte aligned: LDS-DMA destination and ds_read_b128 source
@@ -134,7 +135,15 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     const uint64_t share = (n_cigar + n_waves - 1) / n_waves;
     // one search per wave (its own start); the end is the next wave's start, handed over through LDS
     __shared__ uint64_t split_s[SCAN_WAVES + 1];
-    {
+    __shared__ uint64_t split_w[SCAN_WAVES + 1];
+    if (split) {
+        // the split points depend on the shard and the grid only: a resident shard has them in a table, with the first word of each (five
+        // dependent round trips to HBM per wave in front of its first CIGAR word otherwise)
+        if (threadIdx.x <= SCAN_WAVES) {
+            const uint64_t g = (uint64_t)blockIdx.x * SCAN_WAVES + threadIdx.x;
+            split_s[threadIdx.x] = split[2 * g]; split_w[threadIdx.x] = split[2 * g + 1];
+        }
+    } else {
         const uint64_t b = wave_lower_bound(cigar_off, n_reads, wave_gid * share, lane);
         if (lane == 0) split_s[wave] = b;
         if (wave == SCAN_WAVES - 1) {
@@ -147,8 +156,10 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     const uint64_t r_end = uniform64(split_s[wave + 1]);
 
     // This wave's load stream: the chunks [ring_base, ring_base + 256 ring_total) cover its reads' words.
-    const uint64_t ring_base = uniform64((r_begin < r_end ? cigar_off[r_begin] : 0) & ~(uint64_t)(CHUNK_WORDS - 1));
-    const uint32_t ring_total = uniform32(r_begin < r_end ? (uint32_t)((cigar_off[r_end] - ring_base + CHUNK_WORDS - 1) / CHUNK_WORDS) : 0u);
+    const uint64_t w_begin = split ? uniform64(split_w[wave]) : uniform64(r_begin < r_end ? cigar_off[r_begin] : 0);
+    const uint64_t w_end = split ? uniform64(split_w[wave + 1]) : uniform64(r_begin < r_end ? cigar_off[r_end] : 0);
+    const uint64_t ring_base = w_begin & ~(uint64_t)(CHUNK_WORDS - 1);
+    const uint32_t ring_total = r_begin < r_end ? (uint32_t)((w_end - ring_base + CHUNK_WORDS - 1) / CHUNK_WORDS) : 0u;
     uint32_t ring_ready = 0;              // chunks [0, ring_ready) have landed; chunks [ring_ready, ring_ready + RING_D - 1) are in flight
     for (uint32_t a = 0; a < (uint32_t)(RING_D - 1) && a < ring_total; a++)
         ring_issue(ring[wave][a], cigar, ring_base + (uint64_t)a * CHUNK_WORDS, lane, n_cigar, vec_ok);
@@ -398,27 +409,52 @@ uint32_t scan_start_limit(uint32_t depth_len)
     return b >= 32 ? 0xffffffffu : (1u << b);
 }
 
-void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
-                       uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
-                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &x)
+// persistent-style grid: exactly as many workgroups as are resident at once (waves stride over the reads), so there is no partially
+// filled round of workgroups; two rounds measured best (0.177 ms; 0.191 at one round, 0.179 at three to four, 0.192 at six)
+static unsigned scan_grid(int n_cu, uint64_t n_reads)
 {
-    if (d.n_reads == 0) return;
-    // persistent-style grid: exactly as many workgroups as are resident at once (waves stride over the reads),
-    // so there is no partially filled second round of workgroups
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_kernel, SCAN_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
         blocks_per_cu = occ;
     }
-    uint64_t want = (d.n_reads + SCAN_WAVES - 1) / SCAN_WAVES;
-    // two rounds of workgroups measured best (0.177 ms; 0.191 at one round, 0.179 at three to four, 0.192 at six)
-    uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 2;
-    unsigned grid = (unsigned)(want < cap ? want : cap);
+    const uint64_t want = (n_reads + SCAN_WAVES - 1) / SCAN_WAVES;
+    const uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 2;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+// split[2 g] = first read of wave g of launch_cigar_scan's grid, split[2 g + 1] = that read's first word, g in [0, waves]: one wave per entry, the search the scan's waves would do
+__global__ __launch_bounds__(256) void scan_split_kernel(const uint64_t *__restrict__ cigar_off, uint64_t n_reads, uint64_t n_cigar, uint64_t n_waves,
+                                                        uint64_t *__restrict__ split)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g > n_waves) return;
+    const uint64_t share = (n_cigar + n_waves - 1) / n_waves;
+    const uint64_t b = g >= n_waves ? n_reads : wave_lower_bound(cigar_off, n_reads, g * share, lane_id());
+    if (lane_id() == 0) { split[2 * g] = b; split[2 * g + 1] = cigar_off[b]; }
+}
+
+size_t scan_split_bytes(int n_cu, uint64_t n_reads) { return ((size_t)scan_grid(n_cu, n_reads) * SCAN_WAVES + 1) * 2 * sizeof(uint64_t); }
+
+void launch_scan_split(hipStream_t s, int n_cu, const csv_reads &d, uint64_t *split)
+{
+    if (d.n_reads == 0) return;
+    const uint64_t n_waves = (uint64_t)scan_grid(n_cu, d.n_reads) * SCAN_WAVES;
+    hipLaunchKernelGGL(scan_split_kernel, dim3((unsigned)((n_waves + 1 + 3) / 4)), dim3(256), 0, s, d.cigar_off, d.n_reads, d.n_cigar, n_waves, split);
+}
+
+void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
+                       uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
+                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &x, const uint64_t *split)
+{
+    if (d.n_reads == 0) return;
+    const unsigned grid = scan_grid(n_cu, d.n_reads);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
     hipLaunchKernelGGL(cigar_scan_kernel, dim3(grid), dim3(SCAN_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
                        d.mapq, d.cigar_off, d.cigar, vec_ok, depth_len, scan_start_limit(depth_len), min_oplen, min_mapq, emit, sig_out, sig_cap,
-                       ref_end, q_start, q_end, ckpt, cnt, (unsigned long long *)x.tile_range, x.n_tiles, emit ? x.bucket_hist : nullptr, x.type_pos, x.bucket_shift);
+                       ref_end, q_start, q_end, ckpt, cnt, (unsigned long long *)x.tile_range, x.n_tiles, emit ? x.bucket_hist : nullptr, x.type_pos, x.bucket_shift,
+                       split);
 }
 
 // cigar_off of arrays that already live in HBM (csvgpu_shard_wrap_dev) gets the test the host arrays get in check_reads
