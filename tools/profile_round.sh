@@ -22,11 +22,14 @@ python3 - "$OUT" $((PMC_STEPS + PMC_WARM)) <<'PY'
 import json, sys
 out, n_steps = sys.argv[1], int(sys.argv[2])
 d = json.load(open(out + "/pmc_summary.json"))
-def per_step(k):
-    f = d["FETCH_SIZE"].get(k, {}); w = d["WRITE_SIZE"].get(k, {})
-    return (2 * f.get("mean_KB", 0.0) * f.get("launches", 0) + w.get("mean_KB", 0.0) * w.get("launches", 0)) * 1024 / n_steps
-t = {"wgs": {"depth": per_step("csv::depth_tile_kernel"), "cigar_scan": per_step("csv::cigar_scan_kernel"),
-             "source": "HBM bytes per whole-genome step (24 launches) = sum over launches of (2*FETCH_SIZE + WRITE_SIZE)*1024 / steps, from separate rocprofv3 --pmc passes "
+def per_step(*parts):          # every kernel whose name holds one of `parts` (template instances carry their arguments in the name)
+    tot = 0.0
+    for c, sign in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        for k, v in d[c].items():
+            if any(p in k for p in parts): tot += sign * v.get("mean_KB", 0.0) * v.get("launches", 0)
+    return tot * 1024 / n_steps
+t = {"wgs": {"depth": per_step("depth_tile_kernel", "depth_items_kernel"), "depth_tiles_only": per_step("depth_tile_kernel"), "cigar_scan": per_step("cigar_scan_kernel"),
+             "source": "HBM bytes per whole-genome step (24 launches; depth = the tile kernel + the work-list kernel in front of it) = sum over launches of (2*FETCH_SIZE + WRITE_SIZE)*1024 / steps, from separate rocprofv3 --pmc passes "
                        "of `bench.py --lanes 1 --steps 2 --warmup 1` (" + out.split("/")[-1] + "/pmc_summary.json); FETCH_SIZE doubled per MI355X_MICROARCH.md "
                        "(gfx950 reports half the bytes of wide coalesced reads); read from this committed file by bench.py, not measured in the run"}}
 json.dump(t, open(out + "/pmc_traffic.json", "w"), indent=1)
