@@ -100,18 +100,20 @@ void SNPTable::queryFlat(uint32_t start_pos, uint32_t end_pos, std::vector<uint3
     }
 }
 
-void CNVCaller::prepareWindows(RegionBatch &B, const SNPSource &snps) const
+// SNP look-ups of a batch's regions in chunks of kChunk (independent: one task each), then the window tables
+void CNVCaller::queryChunk(RegionBatch &B, const SNPSource &snps, size_t c) const
 {
     const size_t n = B.regions.size();
-    B.snp.assign((n + kChunk - 1) / kChunk, SnpChunk());
-    B.slot.assign(n, SIZE_MAX);
-    csvhost::parallel_for(B.snp.size(), host_threads, [&](size_t c) {
-        SnpChunk &ch = B.snp[c];
-        for (size_t i = c * kChunk; i < std::min(n, (c + 1) * kChunk); i++) {
-            snps.queryFlat(B.regions[i].first, B.regions[i].second, ch.pos, ch.baf, ch.pfb);
-            ch.off.push_back((uint32_t)ch.pos.size());
-        }
-    });
+    SnpChunk &ch = B.snp[c];
+    for (size_t i = c * kChunk; i < std::min(n, (c + 1) * kChunk); i++) {
+        snps.queryFlat(B.regions[i].first, B.regions[i].second, ch.pos, ch.baf, ch.pfb);
+        ch.off.push_back((uint32_t)ch.pos.size());
+    }
+}
+
+void CNVCaller::finishWindows(RegionBatch &B) const
+{
+    const size_t n = B.regions.size();
     for (size_t i = 0; i < n; i++) {
         const uint32_t start_pos = B.regions[i].first, end_pos = B.regions[i].second;
         if (start_pos > end_pos) {                          // the reference logs and leaves snp_data empty (cnv_caller.cpp:69-73)
@@ -125,6 +127,15 @@ void CNVCaller::prepareWindows(RegionBatch &B, const SNPSource &snps) const
         B.r_start.push_back(start_pos); B.r_end.push_back(end_pos); B.r_ss.push_back(ss);
         B.win_off.push_back(B.win_off.back() + (uint64_t)ss);
     }
+}
+
+void CNVCaller::prepareWindows(RegionBatch &B, const SNPSource &snps) const
+{
+    const size_t n = B.regions.size();
+    B.snp.assign((n + kChunk - 1) / kChunk, SnpChunk());
+    B.slot.assign(n, SIZE_MAX);
+    csvhost::parallel_for(B.snp.size(), host_threads, [&](size_t c) { queryChunk(B, snps, c); });
+    finishWindows(B);
 }
 
 void CNVCaller::launchWindows(RegionBatch &B, csv_shard *shard, double mean_chr_cov) const
@@ -228,7 +239,18 @@ void CNVCaller::observeAndDecode(std::vector<RegionBatch> &batches, const std::v
 {
     {
         csvhost::TraceScope tr("cn: snp queries");
-        for (size_t j = 0; j < jobs.size(); j++) if (!batches[j].regions.empty()) prepareWindows(batches[j], *jobs[j].snps);
+        // the chunks of ALL contigs as one parallel section (24 sections of a few chunks each left most of the pool idle)
+        std::vector<std::pair<uint32_t, uint32_t>> tasks;
+        for (size_t j = 0; j < jobs.size(); j++) {
+            RegionBatch &B = batches[j];
+            const size_t n = B.regions.size();
+            if (!n) continue;
+            B.snp.assign((n + kChunk - 1) / kChunk, SnpChunk());
+            B.slot.assign(n, SIZE_MAX);
+            for (size_t c = 0; c < B.snp.size(); c++) tasks.emplace_back((uint32_t)j, (uint32_t)c);
+        }
+        csvhost::parallel_for(tasks.size(), host_threads, [&](size_t t) { queryChunk(batches[tasks[t].first], *jobs[tasks[t].first].snps, tasks[t].second); });
+        for (size_t j = 0; j < jobs.size(); j++) if (!batches[j].regions.empty()) finishWindows(batches[j]);
     }
     {
         csvhost::TraceScope tr("cn: window launches");

@@ -112,6 +112,8 @@ private:
     struct ObsChunk;
     struct GenomeObs;
     void prepareWindows(RegionBatch &B, const SNPSource &snps) const;
+    void queryChunk(RegionBatch &B, const SNPSource &snps, size_t c) const;
+    void finishWindows(RegionBatch &B) const;
     void launchWindows(RegionBatch &B, csv_shard *shard, double mean_chr_cov) const;
     void assembleRegion(const RegionBatch &B, size_t i, ObsChunk &out) const;
     void observeAndDecode(std::vector<RegionBatch> &batches, const std::vector<ContigJob> &jobs, const CHMM &hmm, GenomeObs &G) const;
