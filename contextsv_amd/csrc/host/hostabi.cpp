@@ -649,7 +649,16 @@ int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *co
         P.overlap_split_prepare = (passes & 16) == 0;
         std::vector<csv_ctx *> lanes(lane_ctxs, lane_ctxs + (n_lanes > 0 ? n_lanes : 0));
         SVCaller caller(ctx);
-        std::unordered_map<std::string, std::vector<SVCall>> calls;
+        // the call map of a genome is 3e4 records with strings in them: it is torn down beside whatever the caller does next (the previous
+        // run's is waited for here), not inside this call
+        static csvhost::WorkerThreads::Ticket teardown = nullptr;
+        if (teardown) { csvhost::WorkerThreads::instance().wait(teardown); teardown = nullptr; }
+        auto calls_p = std::make_shared<std::unordered_map<std::string, std::vector<SVCall>>>();
+        std::unordered_map<std::string, std::vector<SVCall>> &calls = *calls_p;
+        struct Hand {                                                           // (also when runResident throws)
+            std::shared_ptr<std::unordered_map<std::string, std::vector<SVCall>>> &p;
+            ~Hand() { auto dead = std::move(p); teardown = csvhost::WorkerThreads::instance().start([dead]() mutable { dead.reset(); }); }
+        } hand{calls_p};
         std::vector<ChrStats> cs;
         RunStageTimes T;
         caller.runResident(rc, lanes, chmm_from_pod(hmm), P, calls, &cs, &T);

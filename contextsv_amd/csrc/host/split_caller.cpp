@@ -127,7 +127,7 @@ struct ContigWork {
     std::vector<uint32_t> need;                                        // records whose intervals are gathered (sorted)
     std::vector<int32_t> got[3];
     std::vector<PrimaryAlignment> member;
-    std::vector<std::vector<SuppAlignment>> member_supps;
+    std::vector<SuppAlignment> member_supps;           // member m's: [member_supp_off[m - 1], member_supp_off[m]) (one array: 1e4 one-element vectors cost more than the pass's arithmetic)
     std::vector<Group> groups;
     size_t set_base = 0;                           // first of this contig's point sets in the genome-wide batch
     size_t n_primary = 0;
@@ -150,6 +150,9 @@ struct SplitPass::Impl {
     std::vector<ContigWork> work;
     std::vector<SuppRef> supp_index;
     std::vector<std::vector<uint32_t>> dev_recs;
+    std::vector<size_t> need_which;                     // contigs + records whose alignment intervals finish() gathers (built by prepare())
+    std::vector<uint32_t> need_rec;
+    std::vector<uint64_t> need_rec_off;
     Impl(const std::vector<SplitContig> &c, const std::vector<std::string> &t, const SplitParams &p) : contigs(c), target_names(t), params(p) {}
     void prepare();
     void finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
@@ -263,6 +266,25 @@ void SplitPass::Impl::prepare()
     });
 
     printMessage("Removed " + std::to_string(total_removed.load()) + " primary alignments without supplementary alignments");
+
+    // ---- which records' alignment intervals finish() will ask the scan's outputs for (nothing here needs the scan itself) ----------
+    tr.reset(new csvhost::TraceScope("split: need lists"));
+    parallel_over(work.size(), params.threads, [&](size_t c) {
+        ContigWork &W = work[c];
+        if (W.in->ref_end) return;
+        for (uint32_t r : W.member_rec) W.need.push_back(r);
+        for (const SuppRef &sr : W.supps) W.need.push_back(sr.rec);
+        std::sort(W.need.begin(), W.need.end());
+        W.need.erase(std::unique(W.need.begin(), W.need.end()), W.need.end());
+    });
+    need_rec_off.assign(1, 0);
+    for (size_t c = 0; c < work.size(); c++) {
+        ContigWork &W = work[c];
+        if (W.in->ref_end || W.need.empty()) continue;
+        need_which.push_back(c);
+        need_rec.insert(need_rec.end(), W.need.begin(), W.need.end());
+        need_rec_off.push_back(need_rec.size());
+    }
     tr.reset();
 }
 
@@ -273,24 +295,9 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
     // arrays, or — contigs that carry an IntervalSource — gathered for just these records (a few per cent of the contig's) ----------
     tr.reset(new csvhost::TraceScope("split: interval gather"));
     {
-        std::vector<size_t> which;
-        std::vector<uint32_t> rec;
-        std::vector<uint64_t> rec_off{0};
-        parallel_over(work.size(), params.threads, [&](size_t c) {
-            ContigWork &W = work[c];
-            if (W.in->ref_end) return;
-            for (uint32_t r : W.member_rec) W.need.push_back(r);
-            for (const SuppRef &sr : W.supps) W.need.push_back(sr.rec);
-            std::sort(W.need.begin(), W.need.end());
-            W.need.erase(std::unique(W.need.begin(), W.need.end()), W.need.end());
-        });
-        for (size_t c = 0; c < work.size(); c++) {
-            ContigWork &W = work[c];
-            if (W.in->ref_end || W.need.empty()) continue;
-            which.push_back(c);
-            rec.insert(rec.end(), W.need.begin(), W.need.end());
-            rec_off.push_back(rec.size());
-        }
+        const std::vector<size_t> &which = need_which;                             // (the lists were put together by prepare())
+        const std::vector<uint32_t> &rec = need_rec;
+        const std::vector<uint64_t> &rec_off = need_rec_off;
         if (!which.empty()) {
             std::vector<int32_t> a(rec.size()), b(rec.size()), d(rec.size());
             params.intervals->gather(which, rec, rec_off, a.data(), b.data(), d.data());
@@ -316,7 +323,7 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
         const SplitContig &C = *W.in;
         const int primary_tid = C.tid;
         W.member.reserve(W.member_rec.size());
-        W.member_supps.resize(W.member_rec.size());
+        W.member_supps.reserve(W.member_supp_ref.size());
         for (size_t m = 0; m < W.member_rec.size(); m++) {
             const uint32_t i = W.member_rec[m];
             W.member.push_back(PrimaryAlignment{C.pos[i] + 1, interval(W, i, 0), interval(W, i, 1), interval(W, i, 2), !(C.flag[i] & FLAG_REVERSE), 0});
@@ -324,7 +331,7 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
                 const ContigWork &SW = work[W.member_supp_ref[q].first];
                 const SplitContig &S = *SW.in;
                 const uint32_t r = W.member_supp_ref[q].second;
-                W.member_supps[m].push_back(SuppAlignment{S.tid, S.pos[r] + 1, interval(SW, r, 0), interval(SW, r, 1), interval(SW, r, 2), !(S.flag[r] & FLAG_REVERSE)});
+                W.member_supps.push_back(SuppAlignment{S.tid, S.pos[r] + 1, interval(SW, r, 0), interval(SW, r, 1), interval(SW, r, 2), !(S.flag[r] & FLAG_REVERSE)});
             }
         }
 
@@ -353,7 +360,10 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
             for (uint32_t q : members) {
                 const PrimaryAlignment &p = W.member[q];
                 bool opposite = false;
-                for (const SuppAlignment &s : W.member_supps[q]) if (s.tid == primary_tid && s.strand != p.strand) opposite = true;
+                for (size_t z = q ? W.member_supp_off[q - 1] : 0; z < W.member_supp_off[q]; z++) {
+                    const SuppAlignment &s = W.member_supps[z];
+                    if (s.tid == primary_tid && s.strand != p.strand) opposite = true;
+                }
                 n_opposite += opposite;
                 G.sets[0].push_back(p.start);
                 G.sets[1].push_back(p.end);
@@ -361,7 +371,8 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
             G.inversion = (double)n_opposite / (double)(int)members.size() > 0.5;                   // :265
             for (uint32_t q : members) {
                 const PrimaryAlignment &p = W.member[q];
-                for (const SuppAlignment &s : W.member_supps[q]) {
+                for (size_t z = q ? W.member_supp_off[q - 1] : 0; z < W.member_supp_off[q]; z++) {
+                    const SuppAlignment &s = W.member_supps[z];
                     if (s.tid != primary_tid) continue;                                                // translocations: ignored (:352-354)
                     G.sets[2].push_back(s.start);
                     G.sets[3].push_back(s.end);

@@ -276,8 +276,9 @@ class Genome:
             host_threads=0, capacity: int = 1 << 20, host_split_order: bool = False, overlap_split: bool = True):
         """-> (calls[CALL_DTYPE], global tid per call, stage_times, per-contig chr_stats list)"""
         n = len(self)
-        out = np.zeros(capacity, CALL_DTYPE)
-        tid = np.zeros(capacity, np.int32)
+        if getattr(self, "_cap", 0) < capacity:              # result buffers live with the genome (tens of megabytes of page faults per call otherwise)
+            self._out, self._tid, self._cap = np.empty(capacity, CALL_DTYPE), np.empty(capacity, np.int32), capacity
+        out, tid = self._out, self._tid
         k = C.c_uint64(0)
         st = stage_times()
         cs = (chr_stats * max(n, 1))()
