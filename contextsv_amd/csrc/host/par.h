@@ -23,8 +23,16 @@ struct TraceScope {
     const char *name;
     std::chrono::steady_clock::time_point t0;
     static bool on() { static const bool v = [] { const char *e = getenv("CSV_TRACE"); return e && *e && *e != '0'; }(); return v; }
-    explicit TraceScope(const char *n) : name(n) { if (on()) t0 = std::chrono::steady_clock::now(); }
-    ~TraceScope() { if (on()) fprintf(stderr, "[csv trace] %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+    explicit TraceScope(const char *n) : name(n) { if (on()) { (void)origin(); t0 = std::chrono::steady_clock::now(); } }
+    // (the second figure: when the section began, in ms since the first traced section of the process — sections of different threads overlap)
+    static std::chrono::steady_clock::time_point origin() { static const auto o = std::chrono::steady_clock::now(); return o; }
+    ~TraceScope()
+    {
+        if (!on()) return;
+        const auto o = origin();
+        fprintf(stderr, "[csv trace] %-36s %8.3f ms  @ %10.3f\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                std::chrono::duration<double, std::milli>(t0 - o).count());
+    }
 };
 
 class HostPool {

@@ -127,6 +127,7 @@ struct ContigWork {
     std::vector<uint32_t> need;                                        // records whose intervals are gathered (sorted)
     std::vector<int32_t> got[3];
     std::vector<PrimaryAlignment> member;
+    std::vector<uint32_t> member_slot, supp_slot;      // where member m's / supplementary reference q's record sits in its contig's `need` list (prepare())
     std::vector<SuppAlignment> member_supps;           // member m's: [member_supp_off[m - 1], member_supp_off[m]) (one array: 1e4 one-element vectors cost more than the pass's arithmetic)
     std::vector<Group> groups;
     size_t set_base = 0;                           // first of this contig's point sets in the genome-wide batch
@@ -277,6 +278,13 @@ void SplitPass::Impl::prepare()
         std::sort(W.need.begin(), W.need.end());
         W.need.erase(std::unique(W.need.begin(), W.need.end()), W.need.end());
     });
+    parallel_over(work.size(), params.threads, [&](size_t c) {                     // (every contig's list is complete by now)
+        ContigWork &W = work[c];
+        auto slot_of = [](const ContigWork &X, uint32_t rec) { return (uint32_t)(std::lower_bound(X.need.begin(), X.need.end(), rec) - X.need.begin()); };
+        if (!W.in->ref_end) { W.member_slot.reserve(W.member_rec.size()); for (uint32_t r : W.member_rec) W.member_slot.push_back(slot_of(W, r)); }
+        W.supp_slot.reserve(W.member_supp_ref.size());
+        for (const auto &ref : W.member_supp_ref) W.supp_slot.push_back(work[ref.first].in->ref_end ? 0u : slot_of(work[ref.first], ref.second));
+    });
     need_rec_off.assign(1, 0);
     for (size_t c = 0; c < work.size(); c++) {
         ContigWork &W = work[c];
@@ -309,37 +317,39 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
             }
         }
     }
-    auto interval = [&](const ContigWork &W, uint32_t rec, int which) -> int32_t {
-        const SplitContig &C = *W.in;
-        if (C.ref_end) return which == 0 ? C.ref_end[rec] : (which == 1 ? C.q_start[rec] : C.q_end[rec]);
-        const size_t slot = (size_t)(std::lower_bound(W.need.begin(), W.need.end(), rec) - W.need.begin());
-        return W.got[which][slot];
-    };
-
     // ---- phase 2: interval tree, overlap groups, the six point sets (:215-347), per contig ---------------------------------------
     tr.reset(new csvhost::TraceScope("split: groups"));
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         ContigWork &W = work[by_size[k]];
         const SplitContig &C = *W.in;
         const int primary_tid = C.tid;
+        std::unique_ptr<csvhost::TraceScope> t2(k == 0 ? new csvhost::TraceScope("split: groups[0] members") : nullptr);
         W.member.reserve(W.member_rec.size());
         W.member_supps.reserve(W.member_supp_ref.size());
+        // (the records' places in the gathered arrays were looked up by prepare(): no searches on this side of the CIGAR pass)
+        auto at = [](const ContigWork &X, uint32_t rec, uint32_t slot, int which) -> int32_t {
+            const SplitContig &D = *X.in;
+            if (D.ref_end) return which == 0 ? D.ref_end[rec] : (which == 1 ? D.q_start[rec] : D.q_end[rec]);
+            return X.got[which][slot];
+        };
         for (size_t m = 0; m < W.member_rec.size(); m++) {
-            const uint32_t i = W.member_rec[m];
-            W.member.push_back(PrimaryAlignment{C.pos[i] + 1, interval(W, i, 0), interval(W, i, 1), interval(W, i, 2), !(C.flag[i] & FLAG_REVERSE), 0});
+            const uint32_t i = W.member_rec[m], si = C.ref_end ? 0u : W.member_slot[m];
+            W.member.push_back(PrimaryAlignment{C.pos[i] + 1, at(W, i, si, 0), at(W, i, si, 1), at(W, i, si, 2), !(C.flag[i] & FLAG_REVERSE), 0});
             for (size_t q = m ? W.member_supp_off[m - 1] : 0; q < W.member_supp_off[m]; q++) {
                 const ContigWork &SW = work[W.member_supp_ref[q].first];
                 const SplitContig &S = *SW.in;
-                const uint32_t r = W.member_supp_ref[q].second;
-                W.member_supps.push_back(SuppAlignment{S.tid, S.pos[r] + 1, interval(SW, r, 0), interval(SW, r, 1), interval(SW, r, 2), !(S.flag[r] & FLAG_REVERSE)});
+                const uint32_t r = W.member_supp_ref[q].second, sr = W.supp_slot[q];
+                W.member_supps.push_back(SuppAlignment{S.tid, S.pos[r] + 1, at(SW, r, sr, 0), at(SW, r, sr, 1), at(SW, r, sr, 2), !(S.flag[r] & FLAG_REVERSE)});
             }
         }
 
+        if (k == 0) t2.reset(new csvhost::TraceScope("split: groups[0] tree"));
         // overlap groups (:215-238): direct overlaps of the first unprocessed read in iteration order, not transitive
         IntervalTree tree;
         tree.nodes.reserve(W.member.size());
         for (size_t m = 0; m < W.member.size(); m++) tree.add(W.member[m], (uint32_t)m);
         tree.build();
+        if (k == 0) t2.reset(new csvhost::TraceScope("split: groups[0] seeds"));
         std::vector<std::vector<uint32_t>> primary_clusters;
         {
             std::vector<char> processed(W.member.size(), 0);
@@ -352,6 +362,7 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
                 if (group.size() > 1) primary_clusters.push_back(std::move(group));
             }
         }
+        if (k == 0) t2.reset(new csvhost::TraceScope("split: groups[0] sets"));
         W.groups.assign(primary_clusters.size(), Group());
         for (size_t g = 0; g < primary_clusters.size(); g++) {
             Group &G = W.groups[g];

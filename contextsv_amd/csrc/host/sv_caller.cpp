@@ -210,6 +210,7 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
                     hostMerge("shard" + std::to_string(i), slot[i % kSlots], seqs.empty() ? nullptr : seqs[i], calls[i], stats[i]);
                     { std::lock_guard<std::mutex> l(mu); merged[i] = 1; }
                     cv.notify_all();
+                    if (on_merged) on_merged(i);
                 }
             } catch (...) {
                 std::lock_guard<std::mutex> l(mu);
@@ -281,7 +282,8 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
 }
 
 void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double eps, double pct,
-                                    std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats)
+                                    std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats,
+                                    const std::function<void(size_t lane, size_t k)> &on_merged)
 {
     calls.assign(lanes.size(), {});
     stats.assign(lanes.size(), {});
@@ -292,6 +294,7 @@ void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqSto
         threads.push_back(pool.start([&, l] {
             try {
                 SVCaller caller(lanes[l].ctx);
+                if (on_merged) caller.on_merged = [&on_merged, l](size_t k) { on_merged(l, k); };
                 if (!lanes[l].seqs.empty()) caller.processResidentChromosomesPipelined(lanes[l].shards, lanes[l].seqs, eps, pct, calls[l], stats[l]);
                 else caller.processResidentChromosomesPipelined(lanes[l].shards, seq, eps, pct, calls[l], stats[l]);
             } catch (...) { errs[l] = std::current_exception(); }
@@ -462,30 +465,13 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     const size_t n = contigs.size();
     std::vector<ChrStats> stats(n);
     std::vector<std::vector<SVCall>> per(n);
-    // The first half of the split-read pass needs nothing the CIGAR pass produces (flags, name hashes -> the qname map's iteration order):
-    // with lanes, this caller's own context is idle during the CIGAR pass, so that half runs beside it on another thread.
-    std::unique_ptr<SplitSetup> split;
-    csvhost::WorkerThreads::Ticket split_task = nullptr;
-    if (P.split_svs) {
-        split = makeSplitSetup(contigs, P);
-        if (P.cigar_svs && n && lane_ctxs.size() > 1 && P.overlap_split_prepare) {
-            SplitSetup *S = split.get();
-            split_task = csvhost::WorkerThreads::instance().start([S] {
-                const double t0 = now_ms();
-                try { S->pass->prepare(); } catch (...) { S->err = std::current_exception(); }
-                S->ms_prepare = now_ms() - t0;
-            });
-        }
-    }
-    struct JoinSplit {                                                  // the task refers to `split`: never leave this frame with it running
-        csvhost::WorkerThreads::Ticket &t;
-        ~JoinSplit() { if (t) { csvhost::WorkerThreads::instance().wait(t); t = nullptr; } }
-    } join_split{split_task};
+    // contigs over the lanes: longest processing time first by read count, every lane works down its list
+    const size_t L = std::max<size_t>(1, lane_ctxs.size());
+    std::vector<Lane> lanes(L);
+    std::vector<std::vector<size_t>> which(L);
+    std::vector<std::vector<std::vector<SVCall>>> lane_calls;
+    std::vector<std::vector<ChrStats>> lane_stats;
     if (P.cigar_svs && n) {
-        // contigs over the lanes: longest processing time first by read count, every lane works down its list
-        const size_t L = std::max<size_t>(1, lane_ctxs.size());
-        std::vector<Lane> lanes(L);
-        std::vector<std::vector<size_t>> which(L);
         for (size_t l = 0; l < L; l++) lanes[l].ctx = lane_ctxs.empty() ? ctx : lane_ctxs[l];
         std::vector<size_t> order(n);
         for (size_t i = 0; i < n; i++) order[i] = i;
@@ -499,27 +485,89 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
             which[l].push_back(i);
             load[l] += (double)std::max<uint64_t>(contigs[i].split.n, contigs[i].depth_len / 400);
         }
-        std::vector<std::vector<std::vector<SVCall>>> lane_calls;
-        std::vector<std::vector<ChrStats>> lane_stats;
+    }
+    // The first half of the split-read pass needs nothing the CIGAR pass produces (flags, name hashes -> the qname map's iteration order):
+    // with lanes, this caller's own context is idle during the CIGAR pass, so that half runs beside it on another thread. When it is done
+    // the pass is a little over half way: the same thread then makes the CIGAR copy-number predictions of the contigs whose calls are
+    // final by then (own context, the host pool nobody else uses during the pass), and only the rest waits for the end of the pass.
+    struct EarlyCn {
+        std::mutex mu;
+        std::vector<std::pair<size_t, size_t>> merged;     // (lane, k) in the order the merge threads finished them
+        std::vector<char> done;                            // per contig
+        std::exception_ptr err;
+        size_t regions = 0;
+    } early;
+    early.done.assign(n, 0);
+    const bool early_cn = P.cigar_svs && P.cigar_cn && P.split_svs && !P.save_cnv && n && lane_ctxs.size() > 1 && P.overlap_split_prepare && !getenv("CSV_NO_EARLY_CN");
+    std::unique_ptr<SplitSetup> split;
+    csvhost::WorkerThreads::Ticket split_task = nullptr;
+    if (P.split_svs) {
+        split = makeSplitSetup(contigs, P);
+        if (P.cigar_svs && n && lane_ctxs.size() > 1 && P.overlap_split_prepare) {
+            SplitSetup *S = split.get();
+            split_task = csvhost::WorkerThreads::instance().start([&, S] {
+                const double t0 = now_ms();
+                try { S->pass->prepare(); } catch (...) { S->err = std::current_exception(); }
+                S->ms_prepare = now_ms() - t0;
+                if (!early_cn || S->err) return;
+                try {
+                    std::vector<std::pair<size_t, size_t>> snap;
+                    { std::lock_guard<std::mutex> l(early.mu); snap = early.merged; }
+                    static const EmptySnps no_snps;
+                    std::vector<CNVCaller::ContigJob> jobs;
+                    for (const auto &lk : snap) {
+                        const size_t i = which[lk.first][lk.second];
+                        std::vector<SVCall> &v = lane_calls[lk.first][lk.second];
+                        if (v.empty()) continue;
+                        CNVCaller::ContigJob j;
+                        j.chr = contigs[i].name; j.calls = &v; j.mean_chr_cov = lane_stats[lk.first][lk.second].mean_chr_cov; j.shard = contigs[i].shard;
+                        j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
+                        jobs.push_back(j);
+                    }
+                    csvhost::TraceScope tr(jobs.empty() ? "cn: early batch (nothing merged yet)" : "cn: early batch");
+                    if (!jobs.empty()) {
+                        csvhost::set_thread_context(ctx);
+                        CNVCaller cn(ctx);
+                        cn.sample_size = P.sample_size; cn.min_cnv_length = P.min_cnv_length; cn.host_threads = P.host_threads;
+                        early.regions = cn.runCIGARCopyNumberPredictionAll(jobs, hmm);
+                        csvhost::set_thread_context(nullptr);
+                    }
+                    for (const auto &lk : snap) early.done[which[lk.first][lk.second]] = 1;
+                } catch (...) { early.err = std::current_exception(); csvhost::set_thread_context(nullptr); }
+            });
+        }
+    }
+    struct JoinSplit {                                                  // the task refers to this frame: never leave it with the task running
+        csvhost::WorkerThreads::Ticket &t;
+        ~JoinSplit() { if (t) { csvhost::WorkerThreads::instance().wait(t); t = nullptr; } }
+    } join_split{split_task};
+    if (P.cigar_svs && n) {
+        csvhost::TraceScope tr_pass("run: CIGAR pass");
         if (L == 1) {
             lane_calls.resize(1); lane_stats.resize(1);
             SVCaller one(lanes[0].ctx);
             one.min_mapq = min_mapq; one.min_oplen = min_oplen;
             one.processResidentChromosomesPipelined(lanes[0].shards, lanes[0].seqs, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls[0], lane_stats[0]);
         } else {
-            processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats);
+            std::function<void(size_t, size_t)> note;
+            if (early_cn) note = [&early](size_t l, size_t k) { std::lock_guard<std::mutex> g(early.mu); early.merged.emplace_back(l, k); };
+            processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats, note);
         }
+        T.ms_cigar = now_ms() - t_begin;
+        // (the early copy-number batch works on lane_calls in place: it must be over before they move)
+        if (split_task) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
         for (size_t l = 0; l < L; l++)
             for (size_t k = 0; k < which[l].size(); k++) { per[which[l][k]] = std::move(lane_calls[l][k]); stats[which[l][k]] = lane_stats[l][k]; }
-    }
+    } else T.ms_cigar = now_ms() - t_begin;
     for (size_t i = 0; i < n; i++) {                                   // the map is filled in contig order, as run() does
         T.n_signatures += stats[i].n_signatures; T.n_cigar_calls += per[i].size(); T.n_reads += contigs[i].split.n;
         whole_genome_sv_calls[contigs[i].name] = std::move(per[i]);
     }
-    T.ms_cigar = now_ms() - t_begin;
     if (split_task) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
     if (split && split->err) std::rethrow_exception(split->err);
-    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get(), lane_ctxs.size() > 1 ? lane_ctxs[0] : nullptr);
+    if (early.err) std::rethrow_exception(early.err);
+    T.n_cigar_cn_regions += early.regions;
+    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get(), lane_ctxs.size() > 1 ? lane_ctxs[0] : nullptr, early_cn ? &early.done : nullptr);
     T.ms_total = now_ms() - t_begin;
     if (stats_out) *stats_out = stats;
     if (times) *times = T;
@@ -548,7 +596,8 @@ std::unique_ptr<SVCaller::SplitSetup> SVCaller::makeSplitSetup(std::vector<Resid
 }
 
 void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
-                         std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split, csv_ctx *side_ctx)
+                         std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split, csv_ctx *side_ctx,
+                         const std::vector<char> *cigar_cn_done)
 {
     const EmptySnps no_snps;
     csvhost::WorkerThreads::Ticket teardown = nullptr;
@@ -568,11 +617,12 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         printMessage("Saving CNV data to: " + cnv.cnv_output_file);
     }
     double t0 = now_ms();
-    auto cn_jobs = [&](std::unordered_map<std::string, std::vector<SVCall>> &m) {
+    auto cn_jobs = [&](std::unordered_map<std::string, std::vector<SVCall>> &m, const std::vector<char> *skip = nullptr) {
         std::vector<CNVCaller::ContigJob> jobs;
         for (auto &entry : m) {                                                      // the map's own order, as the reference walks it
             if (entry.second.empty()) continue;
             const size_t i = index_of.at(entry.first);
+            if (skip && (*skip)[i]) continue;                                            // (predicted while the CIGAR pass was still running)
             CNVCaller::ContigJob j;
             j.chr = entry.first; j.calls = &entry.second; j.mean_chr_cov = stats[i].mean_chr_cov; j.shard = contigs[i].shard;
             j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
@@ -598,7 +648,7 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
                     csvhost::set_thread_context(side_ctx);
                     CNVCaller side(side_ctx);
                     side.sample_size = cnv.sample_size; side.min_cnv_length = cnv.min_cnv_length; side.host_threads = cnv.host_threads;
-                    std::vector<CNVCaller::ContigJob> jobs = cn_jobs(whole_genome_sv_calls);
+                    std::vector<CNVCaller::ContigJob> jobs = cn_jobs(whole_genome_sv_calls, cigar_cn_done);
                     T.n_cigar_cn_regions += side.runCIGARCopyNumberPredictionAll(jobs, hmm);
                 } catch (...) { cn_err = std::current_exception(); }
                 csvhost::set_thread_context(nullptr);
@@ -606,7 +656,7 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
                 T.ms_cigar_cn = now_ms() - t0;
             });
         } else {
-            std::vector<CNVCaller::ContigJob> jobs = cn_jobs(whole_genome_sv_calls);
+            std::vector<CNVCaller::ContigJob> jobs = cn_jobs(whole_genome_sv_calls, cigar_cn_done);
             T.n_cigar_cn_regions += cnv.runCIGARCopyNumberPredictionAll(jobs, hmm);
             T.ms_cigar_cn = now_ms() - t0;
         }

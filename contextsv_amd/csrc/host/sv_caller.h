@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -137,7 +138,10 @@ public:
     // that their scan + depth pairs run back to back on the gate's stream) and runs processResidentChromosomesPipelined on its shards in its own pair of threads.
     struct Lane { csv_ctx *ctx; std::vector<csv_shard *> shards; std::vector<const SeqStore *> seqs; /* per shard, or empty */ };
     static void processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double dbscan_epsilon, double dbscan_min_pts_pct,
-                                     std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats);
+                                     std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats,
+                                     const std::function<void(size_t lane, size_t k)> &on_merged = {});
+    // called by processResidentChromosomesPipelined's merge threads when shard i's calls and statistics are final (any thread; may be empty)
+    std::function<void(size_t)> on_merged;
 
     // Pass ordering of SVCaller::run (sv_caller.cpp:747-946) over in-memory contigs: depth + CIGAR pass + CIGAR merge per
     // contig -> CIGAR copy-number predictions -> split-read signatures -> their copy-number predictions ->
@@ -178,7 +182,7 @@ private:
     std::unique_ptr<SplitSetup> makeSplitSetup(std::vector<ResidentContig> &contigs, const RunParams &P);
     void finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
                    std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split = nullptr,
-                   csv_ctx *side_ctx = nullptr);
+                   csv_ctx *side_ctx = nullptr, const std::vector<char> *cigar_cn_done = nullptr /* per contig: CIGAR copy-number predictions already made */);
     struct DeviceOut {                       // what the device chain of one shard hands to the host merge: page-locked result buffers
         csv_ctx *ctx = nullptr;
         csv_sig *sig = nullptr;
