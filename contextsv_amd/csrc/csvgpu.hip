@@ -334,7 +334,7 @@ static int dbscan_iv_chain(csv_ctx *ctx, Arena &a, const uint32_t *d_start, cons
     int rc = ensure_pinned(ctx, 4096);
     if (rc) return rc;
     CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     const bool unsorted = *(unsigned int *)ctx->pinned != 0;
     if (!unsorted) {
         TimerScope ts(ctx, CSV_K_DBSCAN);
@@ -422,7 +422,7 @@ void csvgpu_destroy(csv_ctx *ctx)
 int csvgpu_synchronize(csv_ctx *ctx)
 {
     if (!ctx) return CSV_EINVAL;
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -431,7 +431,7 @@ int csvgpu_timing_enable(csv_ctx *ctx, int on) { if (!ctx) return CSV_EINVAL; ct
 int csvgpu_timing_reset(csv_ctx *ctx)
 {
     if (!ctx) return CSV_EINVAL;
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     fold_timers(ctx);
     for (int i = 0; i < CSV_K_COUNT; i++) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
     ctx->timer_tick = 0;
@@ -441,7 +441,7 @@ int csvgpu_timing_reset(csv_ctx *ctx)
 int csvgpu_timing_get(csv_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches)
 {
     if (!ctx || kernel_id < 0 || kernel_id >= CSV_K_COUNT) return CSV_EINVAL;
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     fold_timers(ctx);
     if (total_ms) *total_ms = ctx->t_ms[kernel_id];
     if (launches) *launches = ctx->t_n[kernel_id];
@@ -480,7 +480,7 @@ int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, 
     if (!sortws_carve(ctx->work, n, w) || !sig_sorted) { ctx->err = "arena exhausted (sort)"; return CSV_ENOMEM; }
     order_signatures(ctx, sig_raw, n, depth_len, h.max_start, h.max_len, dr.cnt, false, w, sig_sorted, nullptr, nullptr);
     CSV_HIP(ctx, hipMemcpyAsync(out, sig_sorted, n * sizeof(csv_sig), hipMemcpyDeviceToHost, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -503,7 +503,7 @@ int csvgpu_aln_intervals(csv_ctx *ctx, const csv_reads *reads, int32_t *ref_end,
         CSV_HIP(ctx, hipMemcpyAsync(q_start, dr.q_start, n * 4, hipMemcpyDeviceToHost, ctx->stream));
         CSV_HIP(ctx, hipMemcpyAsync(q_end, dr.q_end, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -568,7 +568,7 @@ int csvgpu_dbscan_iv(csv_ctx *ctx, const uint32_t *start, const uint32_t *end, u
     CSV_HIP(ctx, hipMemcpyAsync(de, end, n * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = csvgpu_dbscan_iv_dev(ctx, ds, de, n, eps, min_pts, dl))) return rc;
     CSV_HIP(ctx, hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -610,7 +610,7 @@ int csvgpu_dbscan_iv_batch(csv_ctx *ctx, const uint32_t *start, const uint32_t *
         }
     }
     CSV_HIP(ctx, hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, st));
-    CSV_HIP(ctx, hipStreamSynchronize(st));
+    CSV_HIP(ctx, wait_stream(st));
     return CSV_OK;
 }
 
@@ -635,7 +635,7 @@ int csvgpu_dbscan_1d_dev(csv_ctx *ctx, const int32_t *d_pts, const uint64_t *d_s
     // segments longer than the LDS kernel's limit: generic sorted-window path, one segment at a time
     std::vector<uint64_t> off(n_seg + 1);
     CSV_HIP(ctx, hipMemcpyAsync(off.data(), d_seg_off, (n_seg + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     SortWs w;
     uint32_t *ks = (uint32_t *)arena_alloc(ctx->work, (size_t)max_seg_len * 4);
     void *tmp = arena_alloc(ctx->work, dbscan1d_big_tmp_bytes(max_seg_len));
@@ -679,7 +679,7 @@ int csvgpu_dbscan_1d(csv_ctx *ctx, const int32_t *pts, const uint64_t *seg_off, 
     CSV_HIP(ctx, hipMemcpyAsync(doff, seg_off, (n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = csvgpu_dbscan_1d_dev(ctx, dp, doff, n_seg, n, (uint32_t)max_len, eps, min_pts, dl))) return rc;
     CSV_HIP(ctx, hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -732,7 +732,7 @@ int csvgpu_window_log2(csv_ctx *ctx, const uint32_t *depth, uint32_t depth_len, 
     CSV_HIP(ctx, hipMemcpyAsync(log2_cov, dl2, nw * 8, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, hipMemcpyAsync(win_start, dws, nw * 4, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, hipMemcpyAsync(win_end, dwe, nw * 4, hipMemcpyDeviceToHost, s));
-    CSV_HIP(ctx, hipStreamSynchronize(s));
+    CSV_HIP(ctx, wait_stream(s));
     return CSV_OK;
 }
 
@@ -782,7 +782,7 @@ int csvgpu_viterbi(csv_ctx *ctx, const csv_hmm *hmm, const double *o1, const dou
     if ((rc = csvgpu_viterbi_dev(ctx, hmm, d1, d2, dp, doff, n_seq, n, dst, dll))) return rc;
     if (n) CSV_HIP(ctx, hipMemcpyAsync(states, dst, n * 4, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, hipMemcpyAsync(loglik, dll, n_seq * 8, hipMemcpyDeviceToHost, s));
-    CSV_HIP(ctx, hipStreamSynchronize(s));
+    CSV_HIP(ctx, wait_stream(s));
     return CSV_OK;
 }
 
@@ -891,7 +891,7 @@ int csvgpu_aln_intervals_resident(csv_ctx *ctx, csv_shard *sh, int32_t *ref_end,
     CSV_HIP(ctx, hipMemcpyAsync(ref_end, sh->ref_end, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     CSV_HIP(ctx, hipMemcpyAsync(q_start, sh->q_start, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     CSV_HIP(ctx, hipMemcpyAsync(q_end, sh->q_end, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -955,7 +955,7 @@ int csvgpu_window_log2_resident_many(csv_ctx *ctx, int n_shards, csv_shard *cons
         }
     }
     CSV_HIP(ctx, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
-    CSV_HIP(ctx, hipStreamSynchronize(s));
+    CSV_HIP(ctx, wait_stream(s));
     w0 = 0;
     for (int c = 0; c < n_shards; c++) {
         const uint64_t nr = n_regions[c];
@@ -1000,7 +1000,7 @@ int csvgpu_aln_intervals_gather_batch(csv_ctx *ctx, int n_shards, csv_shard *con
         launch_gather3_u32(s, (const uint32_t *)sh->ref_end, (const uint32_t *)sh->q_start, (const uint32_t *)sh->q_end, didx + o, m, dout + o, dout + n + o, dout + 2 * n + o);
     }
     CSV_HIP(ctx, hipMemcpyAsync(h_out, dout, 3 * n * 4, hipMemcpyDeviceToHost, s));
-    CSV_HIP(ctx, hipStreamSynchronize(s));
+    CSV_HIP(ctx, wait_stream(s));
     memcpy(ref_end, h_out, n * 4); memcpy(q_start, h_out + n, n * 4); memcpy(q_end, h_out + 2 * n, n * 4);
     return CSV_OK;
 }
@@ -1021,7 +1021,7 @@ int csvgpu_shard_set_qname_hash(csv_ctx *ctx, csv_shard *sh, const uint64_t *qna
         if (hipMalloc((void **)&sh->qhash, n * 8 + 16) != hipSuccess) { (void)hipGetLastError(); sh->qhash = nullptr; ctx->err = "hipMalloc failed (qname hashes)"; return CSV_ENOMEM; }
     }
     if (n) CSV_HIP(ctx, hipMemcpyAsync(sh->qhash, qname_hash, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -1156,7 +1156,7 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
     std::vector<csv_split_survivor> surv(n_surv);
     if (n_surv) {
         CSV_HIP(ctx, hipMemcpyAsync(surv.data(), d_out, n_surv * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
-        CSV_HIP(ctx, hipStreamSynchronize(s));
+        CSV_HIP(ctx, wait_stream(s));
     }
     std::sort(surv.begin(), surv.end(), [](const csv_split_survivor &a, const csv_split_survivor &b) { return a.contig != b.contig ? a.contig < b.contig : a.pos < b.pos; });
     for (const csv_split_survivor &v : surv) out_off[v.contig + 1]++;
@@ -1201,7 +1201,7 @@ int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *reg
     CSV_HIP(ctx, hipMemcpyAsync(log2_cov, dl2, nw * 8, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, hipMemcpyAsync(win_start, dws, nw * 4, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, hipMemcpyAsync(win_end, dwe, nw * 4, hipMemcpyDeviceToHost, s));
-    CSV_HIP(ctx, hipStreamSynchronize(s));
+    CSV_HIP(ctx, wait_stream(s));
     return CSV_OK;
 }
 
@@ -1221,7 +1221,7 @@ int csvgpu_depth_lookup_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *po
     CSV_HIP(ctx, hipMemcpyAsync(dpos, pos, n * 4, hipMemcpyHostToDevice, s));
     csv::launch_depth_lookup(s, sh->depth, sh->depth_len, dpos, n, dout);
     CSV_HIP(ctx, hipMemcpyAsync(depth_out, dout, n * 4, hipMemcpyDeviceToHost, s));
-    CSV_HIP(ctx, hipStreamSynchronize(s));
+    CSV_HIP(ctx, wait_stream(s));
     return CSV_OK;
 }
 
@@ -1233,7 +1233,7 @@ int csvgpu_chr_fetch(csv_ctx *ctx, csv_shard *sh, const csv_chr_result *res, csv
     (void)hipSetDevice(ctx->device);
     CSV_HIP(ctx, hipMemcpyAsync(host_sig, res->sig_del, res->n_sig * sizeof(csv_sig), hipMemcpyDeviceToHost, ctx->stream));
     CSV_HIP(ctx, hipMemcpyAsync(host_labels, res->label_del, res->n_sig * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -1243,7 +1243,7 @@ int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t by
     if (!bytes) return CSV_OK;
     (void)hipSetDevice(ctx->device);
     CSV_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    CSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CSV_HIP(ctx, wait_stream(ctx->stream));
     return CSV_OK;
 }
 
@@ -1468,7 +1468,7 @@ int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host
         }
         if (h.n_sig <= sh->sig_cap) break;
         if (attempt) { ctx->err = "pipeline: signature buffer overflow twice"; return CSV_ENOMEM; }
-        CSV_HIP(ctx, hipStreamSynchronize(s));                            // the queued depth pass reads what the re-run scan rewrites
+        CSV_HIP(ctx, wait_stream(s));                            // the queued depth pass reads what the re-run scan rewrites
         // the larger buffer first: if it cannot be had, the shard keeps its old buffer AND its old capacity (a later job on this
         // shard must never see a capacity without a buffer behind it — the scan's `g < sig_cap` guard would write through null)
         const uint64_t new_cap = h.n_sig + h.n_sig / 8 + 1024;
