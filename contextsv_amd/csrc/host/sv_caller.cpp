@@ -498,6 +498,8 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         size_t regions = 0;
     } early;
     early.done.assign(n, 0);
+    size_t n_lane_contigs = 0;
+    for (size_t l = 0; l < L; l++) n_lane_contigs += which[l].size();
     const bool early_cn = P.cigar_svs && P.cigar_cn && P.split_svs && !P.save_cnv && n && lane_ctxs.size() > 1 && P.overlap_split_prepare && !getenv("CSV_NO_EARLY_CN");
     std::unique_ptr<SplitSetup> split;
     csvhost::WorkerThreads::Ticket split_task = nullptr;
@@ -511,6 +513,12 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                 S->ms_prepare = now_ms() - t0;
                 if (!early_cn || S->err) return;
                 try {
+                    if (getenv("CSV_EARLY_CN_WAIT_ALL")) {                      // tests: every contig through this path, whatever the timing
+                        for (int spin = 0; spin < 200000; spin++) {
+                            { std::lock_guard<std::mutex> l(early.mu); if (early.merged.size() >= n_lane_contigs) break; }
+                            std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        }
+                    }
                     std::vector<std::pair<size_t, size_t>> snap;
                     { std::lock_guard<std::mutex> l(early.mu); snap = early.merged; }
                     static const EmptySnps no_snps;
