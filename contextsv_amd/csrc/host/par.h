@@ -55,10 +55,8 @@ public:
         if (n == 0) return;
         size_t T = threads > 0 ? (size_t)threads : workers_.size() + 1;
         T = std::min(T, std::min(n, workers_.size() + 1));
-        if (T <= 1 || busy_.exchange(true)) {                    // nested or concurrent use: run inline
-            const bool mine = T > 1;
+        if (T <= 1 || busy_.exchange(true)) {                    // one thread asked for, or nested / concurrent use (the flag stays its owner's): run inline
             for (size_t i = 0; i < n; i++) f(i);
-            if (mine) busy_ = false;
             return;
         }
         std::shared_ptr<Job> job = std::make_shared<Job>();

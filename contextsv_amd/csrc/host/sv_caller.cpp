@@ -152,11 +152,20 @@ void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t 
         return;
     }
     const uint64_t type_n[2] = {n_del, n_ins};
-    uint64_t base = 0;
-    for (int t = 0; t < 2; t++) {
-        if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) chr_sv_calls.push_back(toSVCall(sig[base + i], seq));
-        else mergeSignaturesWithLabels(sig + base, labels + base, type_n[t], seq, chr_sv_calls);
-        base += type_n[t];
+    auto one_type = [&](int t, std::vector<SVCall> &dst) {
+        const uint64_t base = t ? n_del : 0;
+        if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) dst.push_back(toSVCall(sig[base + i], seq));
+        else mergeSignaturesWithLabels(sig + base, labels + base, type_n[t], seq, dst);
+    };
+    if (n_del >= 20000 && n_ins >= 20000) {
+        // a large contig's two types side by side when the host pool is free (a rank that holds chr1 alone waits 2.5 ms for this merge;
+        // in a whole-genome pass the lanes' other merges hide it and the pool is usually taken: then the two run one after the other here)
+        std::vector<SVCall> ins_calls;
+        csvhost::parallel_for(2, 2, [&](size_t t) { one_type((int)t, t ? ins_calls : chr_sv_calls); });
+        chr_sv_calls.insert(chr_sv_calls.end(), std::make_move_iterator(ins_calls.begin()), std::make_move_iterator(ins_calls.end()));
+    } else {
+        one_type(0, chr_sv_calls);
+        one_type(1, chr_sv_calls);
     }
 }
 
