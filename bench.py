@@ -283,7 +283,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_step": alg_bytes[dominant], "kernel_ms_per_step": kern.get(dominant, 0.0),
                          "launches_per_step": launches.get(dominant, 0), "launches_timed": int(timing.get(dominant, (0, 0))[1]),
-                         "note": "one launch per contig; achieved = bytes of this rank's contigs per step / the kernel's summed HIP-event time per step "
+                         "note": "one launch per contig (depth = depth_items_kernel + depth_tile_kernel: the tiles' work lists and the tiles); achieved = bytes of this rank's contigs per step / the kernel's summed HIP-event time per step "
                                  "(events on the gate's stream, every launch timed)",
                          "all": {k: {"ms": round(kern.get(k, 0.0), 4), "GBps": round(alg_bytes[k] / (kern[k] * 1e-3) / 1e9, 1) if kern.get(k, 0) > 0 else None}
                                  for k in alg_bytes}},
