@@ -377,6 +377,24 @@ int csvhost_par_selftest(int n_items, int threads)
             for (auto x : t) w.wait(x);
             if (peak != 4) throw std::runtime_error("WorkerThreads: tasks did not run side by side");
         }
+        // several threads in parallel sections at once, two on each pool (the one that finds a pool taken runs its items itself and
+        // leaves the owner's flag alone)
+        std::atomic<long> bad{0};
+        std::vector<csvhost::WorkerThreads::Ticket> t;
+        for (int k = 0; k < 4; k++)
+            t.push_back(w.start([&, k] {
+                if (k & 1) csvhost::HostPool::second_pool_flag() = true;
+                for (int rep = 0; rep < 50; rep++) {
+                    const size_t n = (size_t)n_items / 4 + (size_t)rep + 1;
+                    std::vector<std::atomic<int>> seen(n);
+                    for (auto &h : seen) h = 0;
+                    csvhost::parallel_for(n, threads, [&](size_t i) { seen[i]++; });
+                    for (auto &h : seen) if (h != 1) bad++;
+                }
+                csvhost::HostPool::second_pool_flag() = false;
+            }));
+        for (auto x : t) w.wait(x);
+        if (bad) throw std::runtime_error("parallel_for: concurrent sections lost or repeated an index");
     })
 }
 
