@@ -21,6 +21,7 @@
 #include "par.h"
 #include "umap_order.h"
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <fstream>
 #include <memory>
@@ -669,14 +670,21 @@ int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *co
         SVCaller caller(ctx);
         // the call map of a genome is 3e4 records with strings in them: it is torn down beside whatever the caller does next (the previous
         // run's is waited for here), not inside this call
+        static std::mutex teardown_mu;                                          // (runs of different genomes may come from different threads)
         static csvhost::WorkerThreads::Ticket teardown = nullptr;
-        if (teardown) { csvhost::WorkerThreads::instance().wait(teardown); teardown = nullptr; }
+        auto swap_teardown = [](csvhost::WorkerThreads::Ticket next) {
+            csvhost::WorkerThreads::Ticket prev;
+            { std::lock_guard<std::mutex> l(teardown_mu); prev = teardown; teardown = next; }
+            if (prev) csvhost::WorkerThreads::instance().wait(prev);
+        };
+        swap_teardown(nullptr);
         auto calls_p = std::make_shared<std::unordered_map<std::string, std::vector<SVCall>>>();
         std::unordered_map<std::string, std::vector<SVCall>> &calls = *calls_p;
         struct Hand {                                                           // (also when runResident throws)
             std::shared_ptr<std::unordered_map<std::string, std::vector<SVCall>>> &p;
-            ~Hand() { auto dead = std::move(p); teardown = csvhost::WorkerThreads::instance().start([dead]() mutable { dead.reset(); }); }
-        } hand{calls_p};
+            decltype(swap_teardown) &swap;
+            ~Hand() { auto dead = std::move(p); swap(csvhost::WorkerThreads::instance().start([dead]() mutable { dead.reset(); })); }
+        } hand{calls_p, swap_teardown};
         std::vector<ChrStats> cs;
         RunStageTimes T;
         caller.runResident(rc, lanes, chmm_from_pod(hmm), P, calls, &cs, &T);
