@@ -345,6 +345,15 @@ int csvhost_string_hashes(const char *names, uint64_t n, uint64_t *out)
 
 // Test hook for par.h (CPU): parallel_for visits every index exactly once whatever the thread count, runs nested sections inline, hands
 // the first exception to the caller and stays usable; WorkerThreads runs tasks side by side and reuses its threads. 0 = all held.
+// SVCaller::assignShards: rank_of[i] for every shard weight
+int csvhost_assign_shards(const double *weights, uint64_t n, int world, int32_t *rank_of)
+{
+    GUARD({
+        const std::vector<int> r = SVCaller::assignShards(std::vector<double>(weights, weights + n), world);
+        for (uint64_t i = 0; i < n; i++) rank_of[i] = r[i];
+    })
+}
+
 int csvhost_par_selftest(int n_items, int threads)
 {
     GUARD({

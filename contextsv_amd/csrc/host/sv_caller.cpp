@@ -290,6 +290,23 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
     if (worker_err) std::rethrow_exception(worker_err);
 }
 
+std::vector<int> SVCaller::assignShards(const std::vector<double> &weights, int world)
+{
+    if (world < 1) throw std::invalid_argument("assignShards: world < 1");
+    std::vector<size_t> order(weights.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weights[a] != weights[b] ? weights[a] > weights[b] : a < b; });
+    std::vector<double> load((size_t)world, 0.0);
+    std::vector<int> rank_of(weights.size(), 0);
+    for (size_t i : order) {
+        int r = 0;
+        for (int k = 1; k < world; k++) if (load[(size_t)k] < load[(size_t)r]) r = k;      // (least loaded, lowest rank on ties)
+        rank_of[i] = r;
+        load[(size_t)r] += weights[i];
+    }
+    return rank_of;
+}
+
 void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double eps, double pct,
                                     std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats,
                                     const std::function<void(size_t lane, size_t k)> &on_merged)

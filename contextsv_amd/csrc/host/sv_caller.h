@@ -137,6 +137,11 @@ public:
     // Several chromosomes in flight on one GPU: every lane is a context of its own (own stream; attach one csv_gate to all of them so
     // that their scan + depth pairs run back to back on the gate's stream) and runs processResidentChromosomesPipelined on its shards in its own pair of threads.
     struct Lane { csv_ctx *ctx; std::vector<csv_shard *> shards; std::vector<const SeqStore *> seqs; /* per shard, or empty */ };
+    // Which rank of `world` takes which shard: longest processing time first over the weights (read counts), ties by index — the partition
+    // `contextsv_amd.parallel.assign_shards` makes for bench.py --gpus N (the reference runs the chromosomes as independent pool tasks,
+    // sv_caller.cpp:827-863; a rank's shards are what it stages and passes to runResident, the merged calls are gathered once at the end).
+    static std::vector<int> assignShards(const std::vector<double> &weights, int world);
+
     static void processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double dbscan_epsilon, double dbscan_min_pts_pct,
                                      std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats,
                                      const std::function<void(size_t lane, size_t k)> &on_merged = {});

@@ -138,6 +138,7 @@ def load() -> C.CDLL:
     lib.csvhost_process_resident_chromosome_alts.argtypes = [_P, _P, _P, _P, C.c_double, C.c_double, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.csvhost_par_selftest.argtypes = [C.c_int, C.c_int]
     lib.csvhost_string_hashes.argtypes = [C.c_char_p, C.c_uint64, _P]
+    lib.csvhost_assign_shards.argtypes = [_P, C.c_uint64, C.c_int, _P]
     lib.csvhost_set_quiet(1)
     _hlib = lib
     return lib
@@ -295,6 +296,14 @@ class Genome:
         if self.h:
             load().csvhost_genome_free(self.h)
             self.h = None
+
+
+def assign_shards(weights, world: int) -> list:
+    """SVCaller::assignShards (the C++ mirror of parallel.assign_shards): the shard indices of every rank, ascending."""
+    w = np.ascontiguousarray(weights, np.float64)
+    r = np.zeros(max(len(w), 1), np.int32)
+    _check(load().csvhost_assign_shards(w.ctypes.data, len(w), world, r.ctypes.data))
+    return [[int(i) for i in np.nonzero(r[: len(w)] == k)[0]] for k in range(world)]
 
 
 def string_hashes(names) -> np.ndarray:

@@ -72,3 +72,16 @@ def test_gather_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_cpp_shard_assignment_equals_the_python_one():
+    """SVCaller::assignShards (what a C++ caller of the host mirror uses) makes the partition parallel.assign_shards makes: random weights with
+    ties, more ranks than shards, the benchmark's own contig lengths."""
+    from contextsv_amd import host, parallel
+    rng = np.random.default_rng(5)
+    cases = [list(rng.integers(1, 50, n).astype(float)) for n in (1, 2, 7, 24, 40)] + [[3.0] * 9, [248956422, 242193529, 198295559, 190214555, 181538259, 170805979,
+             159345973, 145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+             46709983, 50818468, 156040895, 57227415]]
+    for w in cases:
+        for world in (1, 2, 3, 4, 8, 30):
+            assert host.assign_shards(w, world) == parallel.assign_shards(w, world)
