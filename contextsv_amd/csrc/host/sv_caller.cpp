@@ -481,6 +481,10 @@ void SVCaller::run(ContigSource &source, const CHMM &hmm, const RunParams &P,
     free_all();
 }
 
+namespace {
+bool env_on(const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; }       // (set, not empty, not "0")
+}  // namespace
+
 void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const std::vector<csv_ctx *> &lane_ctxs, const CHMM &hmm, const RunParams &P,
                            std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, std::vector<ChrStats> *stats_out, RunStageTimes *times)
 {
@@ -526,7 +530,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     early.done.assign(n, 0);
     size_t n_lane_contigs = 0;
     for (size_t l = 0; l < L; l++) n_lane_contigs += which[l].size();
-    const bool early_cn = P.cigar_svs && P.cigar_cn && P.split_svs && !P.save_cnv && n && lane_ctxs.size() > 1 && P.overlap_split_prepare && !getenv("CSV_NO_EARLY_CN");
+    const bool early_cn = P.cigar_svs && P.cigar_cn && P.split_svs && !P.save_cnv && n && lane_ctxs.size() > 1 && P.overlap_split_prepare && !env_on("CSV_NO_EARLY_CN");
     std::unique_ptr<SplitSetup> split;
     csvhost::WorkerThreads::Ticket split_task = nullptr;
     if (P.split_svs) {
@@ -539,7 +543,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                 S->ms_prepare = now_ms() - t0;
                 if (!early_cn || S->err) return;
                 try {
-                    if (getenv("CSV_EARLY_CN_WAIT_ALL")) {                      // tests: every contig through this path, whatever the timing
+                    if (env_on("CSV_EARLY_CN_WAIT_ALL")) {                      // tests: every contig through this path, whatever the timing
                         for (int spin = 0; spin < 200000; spin++) {
                             { std::lock_guard<std::mutex> l(early.mu); if (early.merged.size() >= n_lane_contigs) break; }
                             std::this_thread::sleep_for(std::chrono::microseconds(50));
