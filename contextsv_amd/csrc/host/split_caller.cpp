@@ -151,9 +151,10 @@ struct SplitPass::Impl {
     std::vector<ContigWork> work;
     std::vector<SuppRef> supp_index;
     std::vector<std::vector<uint32_t>> dev_recs;
-    std::vector<size_t> need_which;                     // contigs + records whose alignment intervals finish() gathers (built by prepare())
-    std::vector<uint32_t> need_rec;
-    std::vector<uint64_t> need_rec_off;
+    std::vector<char> grouped;                          // per contig: intervals gathered and overlap groups built (finishEarly() / finish())
+    void gatherFor(const std::vector<size_t> &ids);
+    void groupsOf(size_t c, bool trace);
+    void finishEarly(const std::vector<size_t> &ids);
     Impl(const std::vector<SplitContig> &c, const std::vector<std::string> &t, const SplitParams &p) : contigs(c), target_names(t), params(p) {}
     void prepare();
     void finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
@@ -164,6 +165,7 @@ SplitPass::SplitPass(const std::vector<SplitContig> &contigs, const std::vector<
 SplitPass::~SplitPass() = default;
 void SplitPass::prepare() { p->prepare(); prepared = true; }
 void SplitPass::finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls) { if (!prepared) prepare(); p->finish(sv_calls); }
+void SplitPass::finishEarly(const std::vector<size_t> &contig_ids) { if (prepared) p->finishEarly(contig_ids); }
 
 void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::vector<std::string> &target_names, const SplitParams &params,
                            std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
@@ -285,45 +287,42 @@ void SplitPass::Impl::prepare()
         W.supp_slot.reserve(W.member_supp_ref.size());
         for (const auto &ref : W.member_supp_ref) W.supp_slot.push_back(work[ref.first].in->ref_end ? 0u : slot_of(work[ref.first], ref.second));
     });
-    need_rec_off.assign(1, 0);
-    for (size_t c = 0; c < work.size(); c++) {
-        ContigWork &W = work[c];
-        if (W.in->ref_end || W.need.empty()) continue;
-        need_which.push_back(c);
-        need_rec.insert(need_rec.end(), W.need.begin(), W.need.end());
-        need_rec_off.push_back(need_rec.size());
-    }
+    grouped.assign(work.size(), 0);
     tr.reset();
 }
 
-void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
+// the alignment intervals of these contigs' records (ref_end / q_start / q_end of the scan kernel): straight from the arrays, or — contigs that
+// carry an IntervalSource — gathered for just the records on prepare()'s need lists (a few per cent of the contig's)
+void SplitPass::Impl::gatherFor(const std::vector<size_t> &ids)
 {
-    std::unique_ptr<csvhost::TraceScope> tr;
-    // ---- the alignment intervals of the records that are left (ref_end / q_start / q_end of the scan kernel): straight from the
-    // arrays, or — contigs that carry an IntervalSource — gathered for just these records (a few per cent of the contig's) ----------
-    tr.reset(new csvhost::TraceScope("split: interval gather"));
-    {
-        const std::vector<size_t> &which = need_which;                             // (the lists were put together by prepare())
-        const std::vector<uint32_t> &rec = need_rec;
-        const std::vector<uint64_t> &rec_off = need_rec_off;
-        if (!which.empty()) {
-            std::vector<int32_t> a(rec.size()), b(rec.size()), d(rec.size());
-            params.intervals->gather(which, rec, rec_off, a.data(), b.data(), d.data());
-            for (size_t k = 0; k < which.size(); k++) {
-                ContigWork &W = work[which[k]];
-                W.got[0].assign(a.begin() + (std::ptrdiff_t)rec_off[k], a.begin() + (std::ptrdiff_t)rec_off[k + 1]);
-                W.got[1].assign(b.begin() + (std::ptrdiff_t)rec_off[k], b.begin() + (std::ptrdiff_t)rec_off[k + 1]);
-                W.got[2].assign(d.begin() + (std::ptrdiff_t)rec_off[k], d.begin() + (std::ptrdiff_t)rec_off[k + 1]);
-            }
-        }
+    std::vector<size_t> which;
+    std::vector<uint32_t> rec;
+    std::vector<uint64_t> rec_off{0};
+    for (size_t c : ids) {
+        ContigWork &W = work[c];
+        if (W.in->ref_end || W.need.empty()) continue;
+        which.push_back(c);
+        rec.insert(rec.end(), W.need.begin(), W.need.end());
+        rec_off.push_back(rec.size());
     }
-    // ---- phase 2: interval tree, overlap groups, the six point sets (:215-347), per contig ---------------------------------------
-    tr.reset(new csvhost::TraceScope("split: groups"));
-    parallel_over(contigs.size(), params.threads, [&](size_t k) {
-        ContigWork &W = work[by_size[k]];
+    if (which.empty()) return;
+    std::vector<int32_t> a(rec.size()), b(rec.size()), d(rec.size());
+    params.intervals->gather(which, rec, rec_off, a.data(), b.data(), d.data());
+    for (size_t k = 0; k < which.size(); k++) {
+        ContigWork &W = work[which[k]];
+        W.got[0].assign(a.begin() + (std::ptrdiff_t)rec_off[k], a.begin() + (std::ptrdiff_t)rec_off[k + 1]);
+        W.got[1].assign(b.begin() + (std::ptrdiff_t)rec_off[k], b.begin() + (std::ptrdiff_t)rec_off[k + 1]);
+        W.got[2].assign(d.begin() + (std::ptrdiff_t)rec_off[k], d.begin() + (std::ptrdiff_t)rec_off[k + 1]);
+    }
+}
+
+// phase 2 for one contig: interval tree, overlap groups, the six point sets (:215-347)
+void SplitPass::Impl::groupsOf(size_t c, bool trace)
+{
+        ContigWork &W = work[c];
         const SplitContig &C = *W.in;
         const int primary_tid = C.tid;
-        std::unique_ptr<csvhost::TraceScope> t2(k == 0 ? new csvhost::TraceScope("split: groups[0] members") : nullptr);
+        std::unique_ptr<csvhost::TraceScope> t2(trace ? new csvhost::TraceScope("split: groups[0] members") : nullptr);
         W.member.reserve(W.member_rec.size());
         W.member_supps.reserve(W.member_supp_ref.size());
         // (the records' places in the gathered arrays were looked up by prepare(): no searches on this side of the CIGAR pass)
@@ -339,17 +338,19 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
                 const ContigWork &SW = work[W.member_supp_ref[q].first];
                 const SplitContig &S = *SW.in;
                 const uint32_t r = W.member_supp_ref[q].second, sr = W.supp_slot[q];
+                // (a record on another contig only ever answers the tid tests below, :352-354: its intervals are not looked at — and may not have been gathered yet)
+                if (&SW != &W) { W.member_supps.push_back(SuppAlignment{S.tid, S.pos[r] + 1, 0, 0, 0, !(S.flag[r] & FLAG_REVERSE)}); continue; }
                 W.member_supps.push_back(SuppAlignment{S.tid, S.pos[r] + 1, at(SW, r, sr, 0), at(SW, r, sr, 1), at(SW, r, sr, 2), !(S.flag[r] & FLAG_REVERSE)});
             }
         }
 
-        if (k == 0) t2.reset(new csvhost::TraceScope("split: groups[0] tree"));
+        if (trace) t2.reset(new csvhost::TraceScope("split: groups[0] tree"));
         // overlap groups (:215-238): direct overlaps of the first unprocessed read in iteration order, not transitive
         IntervalTree tree;
         tree.nodes.reserve(W.member.size());
         for (size_t m = 0; m < W.member.size(); m++) tree.add(W.member[m], (uint32_t)m);
         tree.build();
-        if (k == 0) t2.reset(new csvhost::TraceScope("split: groups[0] seeds"));
+        if (trace) t2.reset(new csvhost::TraceScope("split: groups[0] seeds"));
         std::vector<std::vector<uint32_t>> primary_clusters;
         {
             std::vector<char> processed(W.member.size(), 0);
@@ -362,7 +363,7 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
                 if (group.size() > 1) primary_clusters.push_back(std::move(group));
             }
         }
-        if (k == 0) t2.reset(new csvhost::TraceScope("split: groups[0] sets"));
+        if (trace) t2.reset(new csvhost::TraceScope("split: groups[0] sets"));
         W.groups.assign(primary_clusters.size(), Group());
         for (size_t g = 0; g < primary_clusters.size(); g++) {
             Group &G = W.groups[g];
@@ -397,7 +398,31 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
                 }
             }
         }
-    });
+}
+
+// Contigs whose scan outputs exist already (the caller knows): their intervals and groups now, the rest in finish()
+void SplitPass::Impl::finishEarly(const std::vector<size_t> &ids)
+{
+    std::vector<size_t> todo;
+    for (size_t c : ids) if (c < work.size() && !grouped[c]) todo.push_back(c);
+    if (todo.empty()) return;
+    csvhost::TraceScope tr("split: early gather + groups");
+    gatherFor(todo);
+    std::sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return work[a].member_rec.size() > work[b].member_rec.size(); });
+    parallel_over(todo.size(), params.threads, [&](size_t k) { groupsOf(todo[k], false); });
+    for (size_t c : todo) grouped[c] = 1;
+}
+
+void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
+{
+    std::unique_ptr<csvhost::TraceScope> tr;
+    std::vector<size_t> rest;
+    for (size_t k = 0; k < contigs.size(); k++) if (!grouped[by_size[k]]) rest.push_back(by_size[k]);      // (largest first)
+    tr.reset(new csvhost::TraceScope("split: interval gather"));
+    gatherFor(rest);
+    tr.reset(new csvhost::TraceScope("split: groups"));
+    parallel_over(rest.size(), params.threads, [&](size_t k) { groupsOf(rest[k], k == 0); });
+    for (size_t c : rest) grouped[c] = 1;
 
     // ---- the six DBSCAN1D(100, 5) fits of every group of every contig: ONE batched launch (:270-372) ------------------------------
     tr.reset(new csvhost::TraceScope("split: dbscan1d batch"));

@@ -91,6 +91,9 @@ public:
     ~SplitPass();
     void prepare();
     void finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
+    // between the two: contigs (indices into the constructor's list) whose alignment intervals exist already — their interval gather and
+    // overlap groups now instead of inside finish(); any subset, any number of times, after prepare()
+    void finishEarly(const std::vector<size_t> &contig_ids);
 private:
     struct Impl;
     std::unique_ptr<Impl> p;

@@ -393,6 +393,7 @@ struct ShardOrderSource : SplitOrderSource {
 // what the split-read pass of a run works on (built once per run; prepare() may already be running while the CIGAR pass is on the device)
 struct SVCaller::SplitSetup {
     std::vector<SplitContig> blocks;
+    std::vector<int> block_of;                          // per contig of the run: its index in `blocks`, or -1
     std::vector<std::string> names;
     std::unique_ptr<ShardOrderSource> dev_order;
     std::unique_ptr<ShardIntervals> intervals;
@@ -551,6 +552,13 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                     }
                     std::vector<std::pair<size_t, size_t>> snap;
                     { std::lock_guard<std::mutex> l(early.mu); snap = early.merged; }
+                    if (!env_on("CSV_NO_EARLY_SPLIT")) {                        // the same contigs' share of the split pass's second half
+                        std::vector<size_t> blocks;                                // (merged => scanned: their alignment intervals exist)
+                        for (const auto &lk : snap) { const int b = S->block_of[which[lk.first][lk.second]]; if (b >= 0) blocks.push_back((size_t)b); }
+                        csvhost::set_thread_context(ctx);
+                        S->pass->finishEarly(blocks);
+                        csvhost::set_thread_context(nullptr);
+                    }
                     static const EmptySnps no_snps;
                     std::vector<CNVCaller::ContigJob> jobs;
                     for (const auto &lk : snap) {
@@ -618,7 +626,9 @@ std::unique_ptr<SVCaller::SplitSetup> SVCaller::makeSplitSetup(std::vector<Resid
     for (size_t i = 0; i < contigs.size(); i++) {
         ResidentContig &c = contigs[i];
         S->names.push_back(c.name);
+        S->block_of.push_back(-1);
         if (!c.split.qhash || !c.shard || !c.split.n) continue;
+        S->block_of.back() = (int)S->blocks.size();
         c.split.tid = (int32_t)i;
         c.split.ref_end = c.split.q_start = c.split.q_end = nullptr;     // the scan kernel's per-read intervals (the reference's third BAM pass, :137-172) stay in the shards
         S->blocks.push_back(c.split);
