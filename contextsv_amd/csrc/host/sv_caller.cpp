@@ -527,6 +527,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         std::vector<char> done;                            // per contig
         std::exception_ptr err;
         size_t regions = 0;
+        bool pass_over = false;                            // (under mu) the CIGAR pass has returned: the task stops taking batches
     } early;
     early.done.assign(n, 0);
     size_t n_lane_contigs = 0;
@@ -550,35 +551,49 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                             std::this_thread::sleep_for(std::chrono::microseconds(50));
                         }
                     }
-                    std::vector<std::pair<size_t, size_t>> snap;
-                    { std::lock_guard<std::mutex> l(early.mu); snap = early.merged; }
-                    if (!env_on("CSV_NO_EARLY_SPLIT")) {                        // the same contigs' share of the split pass's second half
-                        std::vector<size_t> blocks;                                // (merged => scanned: their alignment intervals exist)
-                        for (const auto &lk : snap) { const int b = S->block_of[which[lk.first][lk.second]]; if (b >= 0) blocks.push_back((size_t)b); }
-                        csvhost::set_thread_context(ctx);
-                        S->pass->finishEarly(blocks);
-                        csvhost::set_thread_context(nullptr);
+                    // One batch now (a little over half the genome is merged), then another whenever a few more contigs are: what is left
+                    // for the end of the pass is the last contigs' share. The pass's end (`pass_over`) ends the loop; whatever was not
+                    // taken here is done behind the pass as before.
+                    size_t taken = 0;
+                    for (bool first = true;; first = false) {
+                        std::vector<std::pair<size_t, size_t>> snap;
+                        bool over;
+                        { std::lock_guard<std::mutex> l(early.mu); snap.assign(early.merged.begin() + (std::ptrdiff_t)taken, early.merged.end()); over = early.pass_over; }
+                        if (!first && (over || snap.size() < 3)) {
+                            if (over) break;
+                            std::this_thread::sleep_for(std::chrono::microseconds(100));
+                            continue;
+                        }
+                        taken += snap.size();
+                        if (!env_on("CSV_NO_EARLY_SPLIT")) {                        // the same contigs' share of the split pass's second half
+                            std::vector<size_t> blocks;                                // (merged => scanned: their alignment intervals exist)
+                            for (const auto &lk : snap) { const int b = S->block_of[which[lk.first][lk.second]]; if (b >= 0) blocks.push_back((size_t)b); }
+                            csvhost::set_thread_context(ctx);
+                            S->pass->finishEarly(blocks);
+                            csvhost::set_thread_context(nullptr);
+                        }
+                        static const EmptySnps no_snps;
+                        std::vector<CNVCaller::ContigJob> jobs;
+                        for (const auto &lk : snap) {
+                            const size_t i = which[lk.first][lk.second];
+                            std::vector<SVCall> &v = lane_calls[lk.first][lk.second];
+                            if (v.empty()) continue;
+                            CNVCaller::ContigJob j;
+                            j.chr = contigs[i].name; j.calls = &v; j.mean_chr_cov = lane_stats[lk.first][lk.second].mean_chr_cov; j.shard = contigs[i].shard;
+                            j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
+                            jobs.push_back(j);
+                        }
+                        csvhost::TraceScope tr(jobs.empty() ? "cn: early batch (nothing merged yet)" : "cn: early batch");
+                        if (!jobs.empty()) {
+                            csvhost::set_thread_context(ctx);
+                            CNVCaller cn(ctx);
+                            cn.sample_size = P.sample_size; cn.min_cnv_length = P.min_cnv_length; cn.host_threads = P.host_threads;
+                            early.regions += cn.runCIGARCopyNumberPredictionAll(jobs, hmm);
+                            csvhost::set_thread_context(nullptr);
+                        }
+                        for (const auto &lk : snap) early.done[which[lk.first][lk.second]] = 1;
+                        if (env_on("CSV_EARLY_CN_WAIT_ALL") || env_on("CSV_EARLY_ONE_BATCH")) break;
                     }
-                    static const EmptySnps no_snps;
-                    std::vector<CNVCaller::ContigJob> jobs;
-                    for (const auto &lk : snap) {
-                        const size_t i = which[lk.first][lk.second];
-                        std::vector<SVCall> &v = lane_calls[lk.first][lk.second];
-                        if (v.empty()) continue;
-                        CNVCaller::ContigJob j;
-                        j.chr = contigs[i].name; j.calls = &v; j.mean_chr_cov = lane_stats[lk.first][lk.second].mean_chr_cov; j.shard = contigs[i].shard;
-                        j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
-                        jobs.push_back(j);
-                    }
-                    csvhost::TraceScope tr(jobs.empty() ? "cn: early batch (nothing merged yet)" : "cn: early batch");
-                    if (!jobs.empty()) {
-                        csvhost::set_thread_context(ctx);
-                        CNVCaller cn(ctx);
-                        cn.sample_size = P.sample_size; cn.min_cnv_length = P.min_cnv_length; cn.host_threads = P.host_threads;
-                        early.regions = cn.runCIGARCopyNumberPredictionAll(jobs, hmm);
-                        csvhost::set_thread_context(nullptr);
-                    }
-                    for (const auto &lk : snap) early.done[which[lk.first][lk.second]] = 1;
                 } catch (...) { early.err = std::current_exception(); csvhost::set_thread_context(nullptr); }
             });
         }
@@ -587,6 +602,10 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         csvhost::WorkerThreads::Ticket &t;
         ~JoinSplit() { if (t) { csvhost::WorkerThreads::instance().wait(t); t = nullptr; } }
     } join_split{split_task};
+    struct EndPass {                                                    // (declared after join_split: runs before it, also when the pass throws)
+        EarlyCn &e;
+        ~EndPass() { std::lock_guard<std::mutex> l(e.mu); e.pass_over = true; }
+    } end_pass{early};
     if (P.cigar_svs && n) {
         csvhost::TraceScope tr_pass("run: CIGAR pass");
         if (L == 1) {
@@ -600,6 +619,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
             processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats, note);
         }
         T.ms_cigar = now_ms() - t_begin;
+        { std::lock_guard<std::mutex> l(early.mu); early.pass_over = true; }
         // (the early copy-number batch works on lane_calls in place: it must be over before they move)
         if (split_task) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
         for (size_t l = 0; l < L; l++)
