@@ -151,10 +151,11 @@ struct SplitPass::Impl {
     std::vector<ContigWork> work;
     std::vector<SuppRef> supp_index;
     std::vector<std::vector<uint32_t>> dev_recs;
-    std::vector<char> grouped;                          // per contig: intervals gathered and overlap groups built (finishEarly() / finish())
+    std::vector<char> grouped, called;                  // per contig: intervals gathered and overlap groups built; calls made and handed out
     void gatherFor(const std::vector<size_t> &ids);
     void groupsOf(size_t c, bool trace);
     void finishEarly(const std::vector<size_t> &ids);
+    void finishFor(const std::vector<size_t> &ids, std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
     Impl(const std::vector<SplitContig> &c, const std::vector<std::string> &t, const SplitParams &p) : contigs(c), target_names(t), params(p) {}
     void prepare();
     void finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
@@ -166,6 +167,7 @@ SplitPass::~SplitPass() = default;
 void SplitPass::prepare() { p->prepare(); prepared = true; }
 void SplitPass::finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls) { if (!prepared) prepare(); p->finish(sv_calls); }
 void SplitPass::finishEarly(const std::vector<size_t> &contig_ids) { if (prepared) p->finishEarly(contig_ids); }
+void SplitPass::finishFor(const std::vector<size_t> &contig_ids, std::unordered_map<std::string, std::vector<SVCall>> &sv_calls) { if (!prepared) prepare(); p->finishFor(contig_ids, sv_calls); }
 
 void findSplitSVSignatures(const std::vector<SplitContig> &contigs, const std::vector<std::string> &target_names, const SplitParams &params,
                            std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
@@ -288,6 +290,7 @@ void SplitPass::Impl::prepare()
         for (const auto &ref : W.member_supp_ref) W.supp_slot.push_back(work[ref.first].in->ref_end ? 0u : slot_of(work[ref.first], ref.second));
     });
     grouped.assign(work.size(), 0);
+    called.assign(work.size(), 0);
     tr.reset();
 }
 
@@ -415,9 +418,20 @@ void SplitPass::Impl::finishEarly(const std::vector<size_t> &ids)
 
 void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
 {
+    std::vector<size_t> all;
+    for (size_t k = 0; k < contigs.size(); k++) all.push_back(by_size[k]);                                  // (largest first)
+    finishFor(all, sv_calls);
+}
+
+// Everything behind prepare() for these contigs (those not done yet): intervals, groups, the DBSCAN1D fits, the calls. A contig's
+// calls depend on nothing outside the contig (records on other contigs only answer tid tests), so any partition of the contigs over
+// calls of this function gives the same calls.
+void SplitPass::Impl::finishFor(const std::vector<size_t> &ids, std::unordered_map<std::string, std::vector<SVCall>> &sv_calls)
+{
     std::unique_ptr<csvhost::TraceScope> tr;
-    std::vector<size_t> rest;
-    for (size_t k = 0; k < contigs.size(); k++) if (!grouped[by_size[k]]) rest.push_back(by_size[k]);      // (largest first)
+    std::vector<size_t> todo, rest;
+    for (size_t c : ids) if (c < work.size() && !called[c]) todo.push_back(c);
+    for (size_t c : todo) if (!grouped[c]) rest.push_back(c);
     tr.reset(new csvhost::TraceScope("split: interval gather"));
     gatherFor(rest);
     tr.reset(new csvhost::TraceScope("split: groups"));
@@ -428,7 +442,8 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
     tr.reset(new csvhost::TraceScope("split: dbscan1d batch"));
     std::vector<int> flat_pts, flat_labels;
     std::vector<uint64_t> flat_off{0};
-    for (ContigWork &W : work) {
+    for (size_t c : todo) {
+        ContigWork &W = work[c];
         W.set_base = flat_off.size() - 1;
         for (Group &G : W.groups)
             for (int s = 0; s < 6; s++) { flat_pts.insert(flat_pts.end(), G.sets[s].begin(), G.sets[s].end()); flat_off.push_back(flat_pts.size()); }
@@ -437,8 +452,8 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
 
     // ---- phase 3: medians, SPLITDIST1 candidates, SPLIT dummies (:283-486), per contig --------------------------------------------
     tr.reset(new csvhost::TraceScope("split: calls"));
-    parallel_over(contigs.size(), params.threads, [&](size_t k) {
-        ContigWork &W = work[by_size[k]];
+    parallel_over(todo.size(), params.threads, [&](size_t k) {
+        ContigWork &W = work[todo[k]];
         if (W.n_primary == 0) return;                        // no entry in primary_map for this tid
         std::vector<SVCall> &chr_sv_calls = W.calls;
         chr_sv_calls.reserve(1000);
@@ -509,7 +524,9 @@ void SplitPass::Impl::finish(std::unordered_map<std::string, std::vector<SVCall>
         mergeDuplicateSVs(chr_sv_calls);
     });
     tr.reset();
-    for (ContigWork &W : work) {
+    for (size_t c : todo) {
+        ContigWork &W = work[c];
+        called[c] = 1;
         if (W.n_primary == 0) continue;
         const std::string chr_name = target_names.at((size_t)W.in->tid);
         printMessage("Processing chromosome " + chr_name + " with " + std::to_string(W.member.size()) + " primary alignments");

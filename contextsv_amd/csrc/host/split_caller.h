@@ -94,6 +94,9 @@ public:
     // between the two: contigs (indices into the constructor's list) whose alignment intervals exist already — their interval gather and
     // overlap groups now instead of inside finish(); any subset, any number of times, after prepare()
     void finishEarly(const std::vector<size_t> &contig_ids);
+    // finish() for a subset of the contigs (those of it not done yet): a contig's calls depend on nothing outside the contig, so any
+    // partition of the contigs over calls gives the calls one finish() gives; finish() afterwards does what is left
+    void finishFor(const std::vector<size_t> &contig_ids, std::unordered_map<std::string, std::vector<SVCall>> &sv_calls);
 private:
     struct Impl;
     std::unique_ptr<Impl> p;

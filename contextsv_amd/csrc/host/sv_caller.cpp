@@ -524,12 +524,14 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     struct EarlyCn {
         std::mutex mu;
         std::vector<std::pair<size_t, size_t>> merged;     // (lane, k) in the order the merge threads finished them
-        std::vector<char> done;                            // per contig
+        std::vector<char> done, finished;                  // per contig: CIGAR copy-number predictions made; every stage of the run made
+        size_t n_split_calls = 0;
         std::exception_ptr err;
         size_t regions = 0;
         bool pass_over = false;                            // (under mu) the CIGAR pass has returned: the task stops taking batches
     } early;
     early.done.assign(n, 0);
+    early.finished.assign(n, 0);
     size_t n_lane_contigs = 0;
     for (size_t l = 0; l < L; l++) n_lane_contigs += which[l].size();
     const bool early_cn = P.cigar_svs && P.cigar_cn && P.split_svs && !P.save_cnv && n && lane_ctxs.size() > 1 && P.overlap_split_prepare && !env_on("CSV_NO_EARLY_CN");
@@ -558,20 +560,18 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                     for (bool first = true;; first = false) {
                         std::vector<std::pair<size_t, size_t>> snap;
                         bool over;
-                        { std::lock_guard<std::mutex> l(early.mu); snap.assign(early.merged.begin() + (std::ptrdiff_t)taken, early.merged.end()); over = early.pass_over; }
+                        size_t unmerged;
+                        { std::lock_guard<std::mutex> l(early.mu); snap.assign(early.merged.begin() + (std::ptrdiff_t)taken, early.merged.end()); over = early.pass_over;
+                          unmerged = n_lane_contigs - early.merged.size(); }
+                        // (a batch takes a few milliseconds beside the pass: with fewer than five contigs still to come the pass would be
+                        // over first and the run would wait for the batch — those go with the rest, behind the pass)
+                        if (!first && unmerged < 5 && !env_on("CSV_EARLY_CN_WAIT_ALL")) break;
                         if (!first && (over || snap.size() < 3)) {
                             if (over) break;
                             std::this_thread::sleep_for(std::chrono::microseconds(100));
                             continue;
                         }
                         taken += snap.size();
-                        if (!env_on("CSV_NO_EARLY_SPLIT")) {                        // the same contigs' share of the split pass's second half
-                            std::vector<size_t> blocks;                                // (merged => scanned: their alignment intervals exist)
-                            for (const auto &lk : snap) { const int b = S->block_of[which[lk.first][lk.second]]; if (b >= 0) blocks.push_back((size_t)b); }
-                            csvhost::set_thread_context(ctx);
-                            S->pass->finishEarly(blocks);
-                            csvhost::set_thread_context(nullptr);
-                        }
                         static const EmptySnps no_snps;
                         std::vector<CNVCaller::ContigJob> jobs;
                         for (const auto &lk : snap) {
@@ -592,6 +592,51 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                             csvhost::set_thread_context(nullptr);
                         }
                         for (const auto &lk : snap) early.done[which[lk.first][lk.second]] = 1;
+                        // ... and everything else the run does with these contigs (:885-927): nothing in it reaches across contigs, so the
+                        // same functions run on this batch's contigs now and on the rest behind the pass
+                        if (!env_on("CSV_NO_EARLY_SPLIT")) {
+                            csvhost::TraceScope tr2("run: early split chain + merges");
+                            csvhost::set_thread_context(ctx);
+                            std::vector<size_t> blocks;                                // (merged => scanned: their alignment intervals exist)
+                            for (const auto &lk : snap) { const int b = S->block_of[which[lk.first][lk.second]]; if (b >= 0) blocks.push_back((size_t)b); }
+                            std::unordered_map<std::string, std::vector<SVCall>> split_calls;
+                            S->pass->finishFor(blocks, split_calls);
+                            std::unordered_map<std::string, std::pair<size_t, size_t>> lane_of;     // contig name -> (lane, k)
+                            for (const auto &lk : snap) lane_of[contigs[which[lk.first][lk.second]].name] = lk;
+                            {
+                                std::vector<CNVCaller::ContigJob> sj;
+                                for (auto &entry : split_calls) {
+                                    if (entry.second.empty()) continue;
+                                    const auto lk = lane_of.at(entry.first);
+                                    const size_t i = which[lk.first][lk.second];
+                                    CNVCaller::ContigJob j;
+                                    j.chr = entry.first; j.calls = &entry.second; j.mean_chr_cov = lane_stats[lk.first][lk.second].mean_chr_cov; j.shard = contigs[i].shard;
+                                    j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
+                                    sj.push_back(j);
+                                }
+                                CNVCaller cn(ctx);
+                                cn.sample_size = P.sample_size; cn.min_cnv_length = P.min_cnv_length; cn.host_threads = P.host_threads;
+                                cn.runSplitReadCopyNumberPredictionsAll(sj, hmm);
+                            }
+                            if (P.merge_split_svs) {
+                                std::vector<std::vector<SVCall> *> sets;
+                                for (auto &entry : split_calls) sets.push_back(&entry.second);
+                                mergeSVsMany(sets, 0.1, 2, true, P.host_threads);
+                            }
+                            for (auto &entry : split_calls) {
+                                const auto lk = lane_of.at(entry.first);
+                                early.n_split_calls += entry.second.size();
+                                std::vector<SVCall> &dst = lane_calls[lk.first][lk.second];
+                                dst.insert(dst.end(), entry.second.begin(), entry.second.end());
+                            }
+                            if (P.merge_final_svs) {
+                                std::vector<std::vector<SVCall> *> sets;
+                                for (const auto &lk : snap) sets.push_back(&lane_calls[lk.first][lk.second]);
+                                mergeSVsMany(sets, 0.1, 2, true, P.host_threads);
+                            }
+                            for (const auto &lk : snap) early.finished[which[lk.first][lk.second]] = 1;
+                            csvhost::set_thread_context(nullptr);
+                        }
                         if (env_on("CSV_EARLY_CN_WAIT_ALL") || env_on("CSV_EARLY_ONE_BATCH")) break;
                     }
                 } catch (...) { early.err = std::current_exception(); csvhost::set_thread_context(nullptr); }
@@ -633,7 +678,9 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     if (split && split->err) std::rethrow_exception(split->err);
     if (early.err) std::rethrow_exception(early.err);
     T.n_cigar_cn_regions += early.regions;
-    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get(), lane_ctxs.size() > 1 ? lane_ctxs[0] : nullptr, early_cn ? &early.done : nullptr);
+    T.n_split_calls += early.n_split_calls;
+    finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get(), lane_ctxs.size() > 1 ? lane_ctxs[0] : nullptr, early_cn ? &early.done : nullptr,
+              early_cn ? &early.finished : nullptr);
     T.ms_total = now_ms() - t_begin;
     if (stats_out) *stats_out = stats;
     if (times) *times = T;
@@ -665,7 +712,7 @@ std::unique_ptr<SVCaller::SplitSetup> SVCaller::makeSplitSetup(std::vector<Resid
 
 void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
                          std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split, csv_ctx *side_ctx,
-                         const std::vector<char> *cigar_cn_done)
+                         const std::vector<char> *cigar_cn_done, const std::vector<char> *finished)
 {
     const EmptySnps no_snps;
     csvhost::WorkerThreads::Ticket teardown = nullptr;
@@ -768,7 +815,10 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
     t0 = now_ms();
     if (P.merge_final_svs) {                                                                                 // :919-927
         std::vector<std::vector<SVCall> *> sets;
-        for (auto &entry : whole_genome_sv_calls) sets.push_back(&entry.second);
+        for (auto &entry : whole_genome_sv_calls) {
+            if (finished && (*finished)[index_of.at(entry.first)]) continue;                                 // (merged while the CIGAR pass was still running)
+            sets.push_back(&entry.second);
+        }
         mergeSVsMany(sets, 0.1, 2, true, P.host_threads);
     }
     T.ms_merge_final = now_ms() - t0;
