@@ -563,9 +563,10 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                         size_t unmerged;
                         { std::lock_guard<std::mutex> l(early.mu); snap.assign(early.merged.begin() + (std::ptrdiff_t)taken, early.merged.end()); over = early.pass_over;
                           unmerged = n_lane_contigs - early.merged.size(); }
-                        // (a batch takes a few milliseconds beside the pass: with fewer than five contigs still to come the pass would be
-                        // over first and the run would wait for the batch — those go with the rest, behind the pass)
-                        if (!first && unmerged < 5 && !env_on("CSV_EARLY_CN_WAIT_ALL")) break;
+                        // (a batch takes a few milliseconds beside the pass: with fewer than eight contigs still to come the pass could be
+                        // over first and the run would wait for the batch — those go with the rest, behind the pass; a rank with a handful of
+                        // contigs never takes one)
+                        if (unmerged < 8 && !env_on("CSV_EARLY_CN_WAIT_ALL")) break;
                         if (!first && (over || snap.size() < 3)) {
                             if (over) break;
                             std::this_thread::sleep_for(std::chrono::microseconds(100));
