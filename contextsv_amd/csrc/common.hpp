@@ -91,6 +91,7 @@ struct csv_shard {
     uint64_t *counters = nullptr;  // device scalars (see ScanCounters) + bucket tables + the depth tiles' candidate ranges, zeroed together per chromosome
     uint64_t *tile_range = nullptr;   // inside `counters`
     uint64_t *scan_split = nullptr;   // the scan's work split for this device's grid (launch_scan_split, once per shard)
+    int       form = 0;               // SCAN_FORM_*: chosen from the mean CIGAR words per read when the shard is created
     void     *depth_items = nullptr;  // depth_items_bytes(depth_len): the depth tiles' work lists (depth.hip)
     uint64_t *qhash = nullptr;        // [n_reads] std::hash<std::string> of every record's query name (csvgpu_shard_set_qname_hash), or null
     size_t    counters_bytes = 0;
@@ -157,12 +158,16 @@ struct ScanExtras {
     uint32_t *bucket_hist = nullptr;  // [BK_N], zeroed: counts of the ordering pass's most-significant-digit buckets; a bucket above BK_LOCAL_MAX is reported in cnt->max_len
     int       type_pos = -1, bucket_shift = 0;
 };
+// Forms of the scan (and of the depth pass's walk): a wave per read (long reads), or groups of 16 / 8 lanes per read (short reads)
+enum { SCAN_FORM_WAVE = 0, SCAN_FORM_ROWS16 = 1, SCAN_FORM_ROWS8 = 2 };
+int scan_form_for(uint64_t n_reads, uint64_t n_cigar);          // by mean CIGAR words per read
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
                        int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &extras = ScanExtras(),
-                       const uint64_t *split = nullptr /* launch_scan_split's table for the same n_cu and shard */);
-size_t scan_split_bytes(int n_cu, uint64_t n_reads);
-void launch_scan_split(hipStream_t s, int n_cu, const csv_reads &d, uint64_t *split);      // once per resident shard
+                       const uint64_t *split = nullptr /* launch_scan_split's table for the same n_cu, shard and form */, int form = SCAN_FORM_WAVE,
+                       uint32_t cigar_pad_words = 0 /* allocated words behind d.cigar[n_cigar] */);
+size_t scan_split_bytes(int n_cu, uint64_t n_reads, int form);
+void launch_scan_split(hipStream_t s, int n_cu, const csv_reads &d, uint64_t *split, int form);      // once per resident shard
 void launch_validate_offsets(hipStream_t s, const uint64_t *cigar_off, uint64_t n_reads, uint64_t n_cigar, uint64_t max_words, uint32_t *bad /* zeroed; set to 1 */);
 uint32_t scan_start_limit(uint32_t depth_len);   // exclusive bound on signature starts that the ordering keys are sized for
 // depth.hip
@@ -181,7 +186,7 @@ void launch_depth_ranges(hipStream_t s, const int32_t *pos_s, const int32_t *pma
 size_t depth_items_bytes(uint32_t depth_len);
 void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *ref_end, const uint32_t *ckpt,
                         uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range, uint32_t cigar_pad_words = 0,
-                        void *items = nullptr);
+                        void *items = nullptr, int form = SCAN_FORM_WAVE /* how the tiles walk their items: SCAN_FORM_* */);
 // reference-offset checkpoints every CKPT_WORDS CIGAR words (scan.hip writes them, depth.hip starts its walks from them)
 constexpr int CKPT_SHIFT = 6, CKPT_WORDS = 1 << CKPT_SHIFT;
 static inline size_t ckpt_bytes(uint64_t n_cigar) { return ((n_cigar >> CKPT_SHIFT) + 2) * sizeof(uint32_t); }

@@ -280,7 +280,8 @@ static void order_signatures(csv_ctx *ctx, const csv_sig *sig_raw, uint64_t n, u
 // depth chain on device arrays. pmax / ord / range scratch comes from `a`; `ranges` != nullptr: the scan already produced the
 // tiles' candidate ranges (coordinate-sorted shard) and only the tile kernel remains.
 static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t *ref_end, const uint32_t *ckpt, bool unsorted, uint32_t depth_len,
-                       uint32_t *depth, ScanCounters *cnt, const uint64_t *ranges = nullptr, uint32_t cigar_pad = 0, void *items = nullptr)
+                       uint32_t *depth, ScanCounters *cnt, const uint64_t *ranges = nullptr, uint32_t cigar_pad = 0, void *items = nullptr,
+                       int form = SCAN_FORM_WAVE)
 {
     const uint64_t n = d.n_reads;
     TimerScope ts(ctx, CSV_K_DEPTH);
@@ -289,7 +290,7 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
         return CSV_OK;
     }
     if (ranges && !unsorted) {
-        launch_depth_tiles(ctx->stream, d, nullptr, ref_end, ckpt, depth_len, depth, cnt, ranges, cigar_pad, items);
+        launch_depth_tiles(ctx->stream, d, nullptr, ref_end, ckpt, depth_len, depth, cnt, ranges, cigar_pad, items, form);
         return CSV_OK;
     }
     int32_t *pmax = (int32_t *)arena_alloc(a, n * 4);
@@ -313,7 +314,7 @@ static int depth_chain(csv_ctx *ctx, Arena &a, const csv_reads &d, const int32_t
     }
     launch_prefix_max(ctx->stream, end_s, pmax, n, ptmp);
     launch_depth_ranges(ctx->stream, pos_s, pmax, n, depth_len, ttmp);
-    launch_depth_tiles(ctx->stream, d, ord, ref_end, ckpt, depth_len, depth, cnt, ttmp, cigar_pad, items);
+    launch_depth_tiles(ctx->stream, d, ord, ref_end, ckpt, depth_len, depth, cnt, ttmp, cigar_pad, items, form);
     return CSV_OK;
 }
 static size_t depth_chain_bytes(uint64_t n, uint32_t depth_len = 0xffffffffu)
@@ -466,7 +467,7 @@ int csvgpu_cigar_scan(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, 
     {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
         launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, min_oplen, min_mapq, 1, sig_raw, cap, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt,
-                          scan_extras(dr.cnt, depth_len, false, nullptr));
+                          scan_extras(dr.cnt, depth_len, false, nullptr), nullptr, scan_form_for(reads->n_reads, reads->n_cigar));
     }
     ScanCounters h;
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
@@ -495,7 +496,8 @@ int csvgpu_aln_intervals(csv_ctx *ctx, const csv_reads *reads, int32_t *ref_end,
     if ((rc = stage_reads(ctx, reads, dr))) return rc;
     {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
-        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, 0, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, 0, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt, ScanExtras(), nullptr,
+                          scan_form_for(reads->n_reads, reads->n_cigar));
     }
     const uint64_t n = reads->n_reads;
     if (n) {
@@ -519,12 +521,14 @@ int csvgpu_depth(csv_ctx *ctx, const csv_reads *reads, uint32_t depth_len, uint3
     if (!d_depth) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN);
-        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt);
+        launch_cigar_scan(ctx->stream, ctx->n_cu, dr.d, depth_len, 0, 0, 0, nullptr, 0, dr.ref_end, dr.q_start, dr.q_end, dr.ckpt, dr.cnt, ScanExtras(), nullptr,
+                          scan_form_for(reads->n_reads, reads->n_cigar));
     }
     ScanCounters h;
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
     if ((rc = arena_reserve(ctx, ctx->work, depth_chain_bytes(reads->n_reads, depth_len)))) return rc;
-    if ((rc = depth_chain(ctx, ctx->work, dr.d, dr.ref_end, dr.ckpt, h.unsorted != 0, depth_len, d_depth, dr.cnt))) return rc;
+    if ((rc = depth_chain(ctx, ctx->work, dr.d, dr.ref_end, dr.ckpt, h.unsorted != 0, depth_len, d_depth, dr.cnt, nullptr, 0, nullptr,
+                          scan_form_for(reads->n_reads, reads->n_cigar)))) return rc;
     if (depth && depth_len) CSV_HIP(ctx, hipMemcpyAsync(depth, d_depth, (size_t)depth_len * 4, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = read_counters(ctx, dr.cnt, h))) return rc;
     if (sum) *sum = h.depth_sum;
@@ -818,12 +822,13 @@ static csv_shard *shard_common(csv_ctx *ctx, csv_shard *sh)
     sh->tile_range = (uint64_t *)((char *)sh->counters + align_up(kCntBytes, 256));
     ok &= hipMalloc((void **)&sh->ckpt, ckpt_bytes(sh->d.n_cigar)) == hipSuccess;
     ok &= hipMalloc(&sh->depth_items, depth_items_bytes(sh->depth_len) + 16) == hipSuccess;
-    ok &= hipMalloc((void **)&sh->scan_split, scan_split_bytes(ctx->n_cu, sh->d.n_reads) + 16) == hipSuccess;
+    sh->form = scan_form_for(sh->d.n_reads, sh->d.n_cigar);
+    ok &= hipMalloc((void **)&sh->scan_split, scan_split_bytes(ctx->n_cu, sh->d.n_reads, sh->form) + 16) == hipSuccess;
     sh->sig_cap = std::max<uint64_t>(1u << 18, n * 2);
     ok &= hipMalloc((void **)&sh->sig_raw, sh->sig_cap * sizeof(csv_sig)) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); ctx->err = "hipMalloc failed (shard)"; shard_release(sh); return nullptr; }
     // the scan's work split for this device's grid, once per shard (the offsets are on the device by now)
-    launch_scan_split(ctx->stream, ctx->n_cu, sh->d, sh->scan_split);
+    launch_scan_split(ctx->stream, ctx->n_cu, sh->d, sh->scan_split, sh->form);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "scan split failed (shard)"; shard_release(sh); return nullptr; }
     return sh;
 }
@@ -1372,14 +1377,14 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
         t0 = get_event(ctx);
         if (t0) CSV_HIP(ctx, hipEventRecord(t0, big));
         launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range), sh->scan_split);
+                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range), sh->owned ? sh->scan_split : nullptr, sh->form, sh->cigar_pad);
     } else if (big != s) {                  // on the gate's stream, not a timed pair: no events of its own
         launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range), sh->scan_split);
+                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sh->tile_range), sh->owned ? sh->scan_split : nullptr, sh->form, sh->cigar_pad);
     } else {
         TimerScope ts(ctx, CSV_K_CIGAR_SCAN, big);
         launch_cigar_scan(big, ctx->n_cu, sh->d, sh->depth_len, job->min_oplen, job->min_mapq, 1, sh->sig_raw, sh->sig_cap, sh->ref_end,
-                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sorted ? sh->tile_range : nullptr), sh->scan_split);
+                          sh->q_start, sh->q_end, sh->ckpt, cnt, scan_extras(cnt, sh->depth_len, true, sorted ? sh->tile_range : nullptr), sh->owned ? sh->scan_split : nullptr, sh->form, sh->cigar_pad);
     }
     job->depth_queued = false;
     if (sh->unsorted >= 0) {
@@ -1396,11 +1401,11 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
         CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, cs));
         CSV_HIP(ctx, hipEventRecord(job->ev_mid, cs));
         if (big != s) {                       // (timed through the pair's events, or not at all)
-            launch_depth_tiles(big, sh->d, nullptr, sh->ref_end, sh->ckpt, sh->depth_len, sh->depth, cnt, sh->tile_range, sh->cigar_pad, sh->depth_items);
+            launch_depth_tiles(big, sh->d, nullptr, sh->ref_end, sh->ckpt, sh->depth_len, sh->depth, cnt, sh->tile_range, sh->cigar_pad, sh->depth_items, sh->form);
         } else {
             ctx->work.used = 0;
             if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt,
-                                  sorted ? sh->tile_range : nullptr, sh->cigar_pad, sh->depth_items))) return rc;
+                                  sorted ? sh->tile_range : nullptr, sh->cigar_pad, sh->depth_items, sh->form))) return rc;
         }
         job->depth_queued = true;
         if (big != s) {
@@ -1505,7 +1510,7 @@ int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host
     // depth map + mean coverage + min_pts (device scalar), unless already queued behind the scan
     if (!job->depth_queued) {
         ctx->work.used = 0;
-        if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt, nullptr, sh->cigar_pad, sh->depth_items))) return rc;
+        if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt, nullptr, sh->cigar_pad, sh->depth_items, sh->form))) return rc;
         launch_min_pts(s, cnt, job->min_pts_pct);
     }
 

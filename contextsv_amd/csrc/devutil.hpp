@@ -43,6 +43,36 @@ __device__ __forceinline__ uint32_t wave_total_dpp(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum_dpp(v), 63);
 }
 
+// ---- groups of GL = 8 or 16 lanes inside a DPP row (the short-read forms of the scan and of the depth walk: a group per read) ----
+// inclusive prefix sum inside every group
+template <int GL>
+__device__ __forceinline__ uint32_t grp_incl_sum(uint32_t v, uint32_t upper)      // upper: all-ones in the upper 8 lanes of a row (GL == 8 only)
+{
+    v += dpp_u32<0x111, 0xf>(0u, v);
+    v += dpp_u32<0x112, 0xf>(0u, v);
+    v += dpp_u32<0x114, 0xf>(0u, v);
+    v += dpp_u32<0x118, 0xf>(0u, v);
+    if (GL == 8) v -= dpp_u32<0x157, 0xf>(0u, v) & upper;          // row_newbcast:7 — the lower group's total leaves the upper group's sums
+    return v;
+}
+// the last lane's value of every group, in all its lanes
+template <int GL>
+__device__ __forceinline__ uint32_t grp_last(uint32_t v)
+{
+    if (GL == 16) return dpp_u32<0x15F, 0xf>(0u, v);                // row_newbcast:15
+    const uint32_t lo = dpp_u32<0x157, 0xf>(0u, v);                 // row_newbcast:7
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)v, 0x15F, 0xf, 0xc, false);   // banks 2, 3 (lanes 8..15) take lane 15's
+}
+template <int GL>
+__device__ __forceinline__ uint32_t grp_min(uint32_t v)
+{
+    v = min(v, dpp_u32<0x111, 0xf>(0xffffffffu, v));
+    v = min(v, dpp_u32<0x112, 0xf>(0xffffffffu, v));
+    v = min(v, dpp_u32<0x114, 0xf>(0xffffffffu, v));                // GL == 8: lane 7 / 15 now hold their group's minimum (a window of 8 lanes)
+    if (GL == 16) v = min(v, dpp_u32<0x118, 0xf>(0xffffffffu, v));
+    return grp_last<GL>(v);
+}
+
 // (a << 2) + b in one instruction (hipcc reassociates the C expression into an add and a shift when b is itself such a sum)
 __device__ __forceinline__ uint32_t lshl2_add(uint32_t a, uint32_t b)
 {

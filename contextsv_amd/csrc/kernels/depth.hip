@@ -282,11 +282,15 @@ __global__ __launch_bounds__(ITEMS_THREADS) void depth_items_kernel(
     const uint64_t T0 = (uint64_t)blockIdx.x * DEPTH_TILE;
     const uint64_t T1 = min(T0 + (uint64_t)DEPTH_TILE, (uint64_t)depth_len);
     const uint64_t k_lo = ~tile_range[2 * (uint64_t)blockIdx.x];
-    const uint64_t k_hi = min(max(k_lo, (uint64_t)tile_range[2 * (uint64_t)blockIdx.x + 1]), k_lo + WL_CAP);
+    // (an empty tile's range is all-zero, k_lo = ~0: candidates are counted from k_lo, never compared with a wrapped-around k_lo + WL_CAP —
+    // that comparison made an empty tile examine the shard's first reads, beyond n_reads in a shard of a few reads)
+    const uint64_t k_top = (uint64_t)tile_range[2 * (uint64_t)blockIdx.x + 1];
+    const uint32_t k_n = k_top > k_lo ? (uint32_t)min(k_top - k_lo, (uint64_t)WL_CAP) : 0u;
     if (threadIdx.x == 0) wl_n = 0;
     __syncthreads();
     DepthItem *__restrict__ const mine = items + (uint64_t)blockIdx.x * WL_CAP;
-    for (uint64_t kk = k_lo + threadIdx.x; kk < k_hi; kk += ITEMS_THREADS) {
+    for (uint32_t i = threadIdx.x; i < k_n; i += ITEMS_THREADS) {
+        const uint64_t kk = k_lo + i;
         DepthItem it;
         if (depth_make_item<8>(ord ? (uint64_t)ord[kk] : kk, T0, T1, pos, flag, cigar_off, ref_end, ckpt, it))
             *reinterpret_cast<uint4 *>(&mine[atomicAdd(&wl_n, 1u)]) = *reinterpret_cast<const uint4 *>(&it);
@@ -308,7 +312,9 @@ extern "C" void csvgpu_debug_depth_phase(unsigned long long *out, int reset)
 #endif
 // PADDED: the CIGAR array is 16-byte aligned and followed by at least 4 * WAVE allocated words (csvgpu_shard_upload's own arrays):
 // every chunk load is one unconditional 16-byte load per lane.
-template <bool PADDED>
+// GL: lanes that walk one item together — 64 (a wave per item, the stream of 1 KiB chunks below: long reads) or 16 / 8 (short reads:
+// a (tile, read) item of a HiFi shard is 40 words, and a whole wave per item left 5 lanes in 6 idle; 64-word windows, see scan.hip).
+template <bool PADDED, int GL>
 __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int vec_ok, int dvec_ok,
@@ -378,7 +384,83 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
         // STATIC indices (the loop is unrolled by the ring's size; a buffer is refilled in place the moment its words have been decoded).
         // Every step issues exactly one load (a repeat of the last address once the stream has run dry), so the compiler's vmcnt counts
         // stay exact. What the consumer needs to know about a buffer's chunk travels in scalar registers next to it.
-        if (n_items) {
+        if constexpr (GL != WAVE) {
+            // Short reads: every group of GL lanes takes the items gid, gid + n_groups, ... of the list and walks each in 64-word windows from the
+            // item's first valid word rounded down to 16 bytes (an item of a HiFi shard is one window); the next window's words — the next
+            // item's, usually — are requested before the current one is decoded. Same arithmetic as the stream below, per group.
+            constexpr int WPL = WAVE / GL;
+            constexpr uint32_t NGRP = DEPTH_THREADS / GL;
+            const uint32_t sub = threadIdx.x & (uint32_t)(GL - 1), gid = threadIdx.x / (uint32_t)GL;
+            const uint32_t upper = (lane & 8) ? 0xffffffffu : 0u;
+            auto loadw = [&](uint32_t g, uint32_t (&ww)[WPL]) {
+                if (PADDED) {
+#pragma unroll
+                    for (int q = 0; q < WPL; q += 4) {
+                        const uint4 x = *reinterpret_cast<const uint4 *>(cigar + g + q);
+                        ww[q] = x.x; ww[q + 1] = x.y; ww[q + 2] = x.z; ww[q + 3] = x.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < WPL; k++) ww[k] = ((uint64_t)g + k < n_cigar) ? cigar[g + k] : (uint32_t)OP_P;
+                }
+            };
+            uint32_t it = gid;
+            bool act = it < n_items;
+            uint4 cd = *reinterpret_cast<const uint4 *>(&wl[act ? it : 0u]);       // {b0, nrem, pack, start}
+            uint32_t v = 0;
+            int32_t base_rel = 0;
+            uint32_t ww[WPL];
+            loadw(act ? (((cd.x << CKPT_SHIFT) + (cd.z & 63u)) & ~3u) + sub * WPL : 0u, ww);
+            while (__ballot(act)) {
+                const uint32_t fv = (cd.x << CKPT_SHIFT) + (cd.z & 63u);            // first valid word (32-bit word indices: the short-read forms are only chosen below 2^32 words)
+                const uint32_t nval = act ? cd.y - (cd.z & 63u) : 0u;             // valid words from there
+                const uint32_t a = fv & ~3u;
+                const uint32_t n_win = max(1u, (fv - a + nval + 63u) >> 6);
+                const bool last = v + 1 >= n_win;
+                const uint32_t nit = last ? it + NGRP : it;
+                const bool nact = act && nit < n_items;
+                uint4 nd = cd;
+                if (last) nd = *reinterpret_cast<const uint4 *>(&wl[nact ? nit : 0u]);
+                const uint32_t nv = last ? 0u : v + 1u;
+                uint32_t wn[WPL];
+                loadw(nact ? (((nd.x << CKPT_SHIFT) + (nd.z & 63u)) & ~3u) + nv * 64u + sub * WPL : 0u, wn);
+
+                if (v == 0) base_rel = (int32_t)cd.w;
+                const uint32_t t = a + v * 64u + sub * WPL - fv;
+                uint32_t rl[WPL], gp[WPL], lane_ref = 0;
+#pragma unroll
+                for (int k = 0; k < WPL; k++) {
+                    if (!((uint32_t)(t + k) < nval)) ww[k] = (uint32_t)OP_P;
+                    const uint32_t len = ww[k] >> 4;
+                    rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), ww[k], 1u);
+                    gp[k] = (uint32_t)__builtin_amdgcn_sbfe((int)(GAP_OPS | (GAP_OPS << 16)), ww[k], 1u);
+                    lane_ref += rl[k];
+                }
+                const uint32_t incl = grp_incl_sum<GL>(lane_ref, upper);
+                const int32_t total = (int32_t)grp_last<GL>(incl);
+                {   // the window's share of the read's span, clipped to the tile
+                    const int32_t sa = clamp0_i32(base_rel, TW), sb = clamp0_i32(base_rel + total, TW);
+                    if (act && sa != sb && sub < 2) atomicAdd(&diff[sub ? sb : sa], sub ? 0xffffffffu : 1u);
+                }
+                {
+                    int32_t rel = base_rel + (int32_t)(incl - lane_ref), ca = clamp0_i32(rel, TW);
+#pragma unroll
+                    for (int k = 0; k < WPL; k++) {
+                        rel += (int32_t)rl[k];
+                        const int32_t cb2 = clamp0_i32(rel, TW);
+                        if (gp[k]) {
+                            atomicAdd(&diff[ca], 0xffffffffu);
+                            atomicAdd(&diff[cb2], 1u);
+                        }
+                        ca = cb2;
+                    }
+                }
+                base_rel += total;
+                if (last) { v = 0; it = nit; cd = nd; act = nact; } else v = nv;
+#pragma unroll
+                for (int k = 0; k < WPL; k++) ww[k] = wn[k];
+            }
+        } else if (n_items) {
             uint32_t w[DEPTH_PF + 1][4];
             uint32_t m_o0[DEPTH_PF + 1], m_nrem[DEPTH_PF + 1], m_c0rel[DEPTH_PF + 1];
             int32_t m_start[DEPTH_PF + 1];
@@ -562,7 +644,7 @@ void launch_depth_ranges(hipStream_t s, const int32_t *pos_s, const int32_t *pma
 size_t depth_items_bytes(uint32_t depth_len) { return align_up((size_t)depth_n_tiles(depth_len) * (WL_CAP * sizeof(DepthItem) + sizeof(uint32_t)), 256); }
 
 void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, const int32_t *ref_end, const uint32_t *ckpt,
-                        uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range, uint32_t cigar_pad_words, void *items)
+                        uint32_t depth_len, uint32_t *depth, ScanCounters *cnt, const uint64_t *tile_range, uint32_t cigar_pad_words, void *items, int form)
 {
     if (depth_len == 0) return;
     const unsigned tiles = depth_n_tiles(depth_len);
@@ -572,12 +654,15 @@ void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, 
     uint32_t *n_it = items ? (uint32_t *)(it + (size_t)tiles * WL_CAP) : nullptr;
     if (items)
         hipLaunchKernelGGL(depth_items_kernel, dim3(tiles), dim3(ITEMS_THREADS), 0, s, d.pos, d.flag, d.cigar_off, ord, ref_end, tile_range, ckpt, depth_len, it, n_it);
-    if (vec_ok && cigar_pad_words >= 4 * WAVE)
-        hipLaunchKernelGGL(depth_tile_kernel<true>, dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
-                           d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt, it, n_it);
-    else
-        hipLaunchKernelGGL(depth_tile_kernel<false>, dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
-                           d.cigar_off, d.cigar, vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt, it, n_it);
+    if (form != SCAN_FORM_WAVE && d.n_cigar >= 0xffffffffull) form = SCAN_FORM_WAVE;
+    const bool padded = vec_ok && cigar_pad_words >= 4 * WAVE;
+#define CSV_TILE_LAUNCH(PAD, GL)                                                                                                                 \
+    hipLaunchKernelGGL((depth_tile_kernel<PAD, GL>), dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag, d.cigar_off, d.cigar, \
+                       vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt, it, n_it)
+    if (form == SCAN_FORM_ROWS16) { if (padded) CSV_TILE_LAUNCH(true, 16); else CSV_TILE_LAUNCH(false, 16); }
+    else if (form == SCAN_FORM_ROWS8) { if (padded) CSV_TILE_LAUNCH(true, 8); else CSV_TILE_LAUNCH(false, 8); }
+    else { if (padded) CSV_TILE_LAUNCH(true, WAVE); else CSV_TILE_LAUNCH(false, WAVE); }
+#undef CSV_TILE_LAUNCH
 }
 
 // min_pts = (int)ceil(mean_cov * pct), or 5 when pct <= 0 (sv_caller.cpp:723-728); mean = sum / #non-zero

@@ -400,6 +400,299 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------- short-read form
+// The same walk for shards of SHORT reads (PacBio HiFi: ~40 ops per read; BASELINE configs[4]): a wave per read spends a whole 256-word
+// visit on 40 words and pays the per-read prologue once per 160 bytes. Here a GROUP of GL lanes (8 or 16) owns a read, 64 / GL reads
+// are in flight per wave, a window is 64 words (64 / GL per lane) starting at the read's first word rounded down to 16 bytes — a
+// 40-word read is one window — and every group runs through ITS reads at its own pace (the groups of a wave share nothing but the
+// instruction stream): per-read state lives in vector registers, the cursors are group prefix sums (DPP row shifts; row_newbcast for
+// the totals), per-read metadata reaches the groups through a 1 KiB LDS table per wave (one 16-byte broadcast read per read), and the
+// words of a group's NEXT window — the next read's first, usually — are requested before the current one is decoded.
+// Same outputs as cigar_scan_kernel, word for word (signatures as a set: the ordering pass fixes the order).
+// The depth tiles' candidate ranges go through a per-workgroup LDS table first (a workgroup's reads reach a handful of tiles, and at
+// 60x every tile is reached by a hundred reads: two same-address device atomics per (read, tile) otherwise).
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / WAVE;
+constexpr int rs_occ(int gl) { return gl == 8 ? 5 : 8; }    // workgroups per CU the registers allow (8 words per lane and their prefetch: 96 registers)
+constexpr uint32_t TR_SLOTS = 64;            // depth tiles (from the workgroup's first read's tile on) whose ranges are combined in LDS
+constexpr uint32_t RS_MIN_READS = 32;        // reads per wave below which the grid shrinks instead
+
+template <int GL, bool PADDED>
+__global__ __launch_bounds__(RS_THREADS, rs_occ(GL)) void cigar_scan_rows_kernel(
+    uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
+    const uint8_t *__restrict__ mapq, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
+    uint32_t depth_len, uint32_t start_limit, uint32_t min_oplen, uint32_t min_mapq, int emit,
+    csv_sig *__restrict__ sig_out, uint64_t sig_cap, int32_t *__restrict__ ref_end, int32_t *__restrict__ q_start,
+    int32_t *__restrict__ q_end, uint32_t *__restrict__ ckpt, ScanCounters *__restrict__ cnt,
+    unsigned long long *__restrict__ tile_range, uint32_t n_tiles, uint32_t *__restrict__ bucket_hist, int hist_type_pos, int hist_shift,
+    const uint64_t *__restrict__ split)
+{
+    constexpr int WPL = WAVE / GL;            // words per lane per window
+    constexpr int NG = WAVE / GL;             // groups = reads in flight per wave
+    __shared__ csv_sig buf[SIG_BUF];
+    __shared__ alignas(16) uint4 meta[RS_WAVES][WAVE];               // {first word, words, pos, flag | mapq << 16} of the wave's current 64 reads
+    __shared__ uint32_t tr_first[TR_SLOTS], tr_last[TR_SLOTS];
+    __shared__ uint32_t buf_n, blk_n_del, blk_overflow, tr_base;
+    __shared__ unsigned long long blk_gbase;
+    __shared__ uint64_t split_s[RS_WAVES + 1];
+
+    const int lane = lane_id();
+    const int wave = (int)uniform32(threadIdx.x >> 6);
+    const uint32_t sub = (uint32_t)lane & (uint32_t)(GL - 1);       // lane within its group
+    const uint32_t grp = (uint32_t)lane / (uint32_t)GL;
+    const uint32_t upper = (lane & 8) ? 0xffffffffu : 0u;
+    if (threadIdx.x == 0) { buf_n = 0; blk_n_del = 0; blk_overflow = 0; }
+    if (threadIdx.x < TR_SLOTS) { tr_first[threadIdx.x] = 0; tr_last[threadIdx.x] = 0; }
+
+    const uint64_t n_waves = (uint64_t)gridDim.x * RS_WAVES;
+    const uint64_t wave_gid = (uint64_t)blockIdx.x * RS_WAVES + wave;
+    const uint64_t share = (n_cigar + n_waves - 1) / n_waves;
+    if (split) {
+        if (threadIdx.x <= RS_WAVES) split_s[threadIdx.x] = split[2 * ((uint64_t)blockIdx.x * RS_WAVES + threadIdx.x)];
+    } else {
+        const uint64_t b = wave_lower_bound(cigar_off, n_reads, wave_gid * share, lane);
+        if (lane == 0) split_s[wave] = b;
+        if (wave == RS_WAVES - 1) {
+            const uint64_t e = (wave_gid + 1 >= n_waves) ? n_reads : wave_lower_bound(cigar_off, n_reads, (wave_gid + 1) * share, lane);
+            if (lane == 0) split_s[RS_WAVES] = e;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t r0 = split_s[0];
+        tr_base = (tile_range && r0 < n_reads) ? (((uint32_t)pos[r0] + 1u) >> DEPTH_TILE_SHIFT) : 0u;
+    }
+    __syncthreads();
+    const uint64_t r_begin = uniform64(split_s[wave]);
+    const uint64_t r_end = uniform64(split_s[wave + 1]);
+    const uint32_t tbase = tr_base;
+
+    uint32_t my_n_del = 0, my_overflow = 0, my_bucket_max = 0;
+
+    // one window's words of this lane: words [g, g + WPL) of the array (g a multiple of 4)
+    auto loadw = [&](uint32_t g, uint32_t (&w)[WPL]) {
+        if (PADDED) {
+#pragma unroll
+            for (int q = 0; q < WPL; q += 4) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(cigar + g + q);
+                w[q] = x.x; w[q + 1] = x.y; w[q + 2] = x.z; w[q + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < WPL; k++) w[k] = ((uint64_t)g + k < n_cigar) ? cigar[g + k] : (uint32_t)OP_P;
+        }
+    };
+
+    for (uint64_t rb = r_begin; rb < r_end; rb += WAVE) {
+        const uint32_t nb = (uint32_t)min((uint64_t)WAVE, r_end - rb);
+        {   // the batch's metadata, lane-parallel and coalesced
+            uint4 m = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t l_uns = 0;
+            if ((uint32_t)lane < nb) {
+                const uint64_t rr = rb + lane;
+                const uint64_t c0 = cigar_off[rr], c1 = cigar_off[rr + 1];
+                const int32_t p = pos[rr];
+                m = make_uint4((uint32_t)c0, (uint32_t)(c1 - c0), (uint32_t)p, (uint32_t)flag[rr] | ((uint32_t)mapq[rr] << 16));
+                l_uns = (rr > 0 && p < pos[rr - 1]) ? 1u : 0u;
+            }
+            if (__ballot(l_uns != 0) && lane == 0) cnt->unsorted = 1u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            meta[wave][lane] = m;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // group `grp` takes the batch's reads grp, grp + NG, ...; every loop step is one window of every group's current read
+        uint32_t slot = grp;
+        bool act = slot < nb;
+        uint4 cm = meta[wave][act ? slot : 0u];
+        uint32_t v = 0;                        // window of the current read
+        uint32_t ref_carry = 0, q_carry = 0, skip_carry = 0;
+        int32_t qs = -1;
+        uint32_t w[WPL];
+        loadw(act ? (cm.x & ~3u) + sub * WPL : 0u, w);
+        while (__ballot(act)) {
+            const uint32_t c0 = cm.x, nw = act ? cm.y : 0u, p0 = cm.z, fl = cm.w & 0xffffu, mq = cm.w >> 16;
+            const uint32_t a = c0 & ~3u;
+            const uint32_t n_win = max(1u, (c0 - a + nw + 63u) >> 6);
+            const bool last = v + 1 >= n_win;
+            // the group's next window: the next one of this read, or the first one of its next read
+            const uint32_t nslot = last ? slot + NG : slot;
+            const bool nact = act && nslot < nb;
+            uint4 nm = cm;
+            if (last) nm = meta[wave][nact ? nslot : 0u];
+            const uint32_t nv = last ? 0u : v + 1u;
+            uint32_t wn[WPL];
+            loadw(nact ? (nm.x & ~3u) + nv * 64u + sub * WPL : 0u, wn);
+
+            // ---- window v of the current read ------------------------------------------------------------------------
+            const uint64_t r = rb + slot;
+            const uint32_t g = a + v * 64u + sub * WPL;                  // this lane's first word
+            const uint32_t t = g - c0;                                   // ... relative to the read's first word (wraps in front of it)
+            // sv_caller.cpp:526
+            const bool emit_ok = emit && act && !(fl & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && mq >= min_mapq;
+            uint32_t lane_ref = 0, lane_q = 0, trig = 0;
+#pragma unroll
+            for (int k = 0; k < WPL; k++) {
+                if (!((uint32_t)(t + k) < nw)) w[k] = (uint32_t)OP_P;    // words of the neighbouring reads (and everything of an idle group)
+                const uint32_t len = w[k] >> 4;
+                const uint32_t rl = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), w[k], 1u);
+                const uint32_t ql = len & (uint32_t)__builtin_amdgcn_sbfe((int)(QRY_OPS | (QRY_OPS << 16)), w[k], 1u);
+                lane_ref += rl; lane_q += ql;
+                trig |= rl ^ ql;
+            }
+            const uint32_t incl_ref = grp_incl_sum<GL>(lane_ref, upper);
+            const uint32_t incl_q = grp_incl_sum<GL>(lane_q, upper);
+            const uint32_t tot_ref = grp_last<GL>(incl_ref), tot_q = grp_last<GL>(incl_q);
+            const uint32_t ro = ref_carry + (incl_ref - lane_ref);       // reference offset in front of this lane's first word
+            const uint32_t qp = q_carry + (incl_q - lane_q);             // plain query cursor there
+            // checkpoints: the read's reference offset at every CKPT_WORDS-th word strictly inside it (a lane's words start at a multiple of 4)
+            {
+                if ((g & (uint32_t)(CKPT_WORDS - 1)) == 0 && t - 1u < nw - 1u && nw) ckpt[g >> CKPT_SHIFT] = ro;
+                if (WPL == 8 && ((g + 4u) & (uint32_t)(CKPT_WORDS - 1)) == 0 && t + 3u < nw - 1u && nw) {
+                    uint32_t x = ro;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) x += (w[k] >> 4) & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), w[k], 1u);
+                    ckpt[(g + 4u) >> CKPT_SHIFT] = x;
+                }
+            }
+            // query_start = cursor at the first M/I/=/X op (sv_caller.cpp:674-676)
+            if (__ballot(qs < 0 && act)) {
+                // (cursors grow with the lane: the group's minimum over the lanes that hold such an op is the first one's)
+                uint32_t q_at = 0xffffffffu, acc = qp;
+                bool found = false;
+#pragma unroll
+                for (int k = 0; k < WPL; k++) {
+                    const uint32_t op = w[k] & 15u;
+                    if (!found && ((QST_OPS >> op) & 1u)) { found = true; q_at = acc; }
+                    acc += (w[k] >> 4) & (uint32_t)__builtin_amdgcn_sbfe((int)(QRY_OPS | (QRY_OPS << 16)), w[k], 1u);
+                }
+                const uint32_t first = grp_min<GL>(q_at);
+                if (qs < 0 && first != 0xffffffffu) qs = (int32_t)first;
+            }
+            uint32_t skip_tot = 0;
+            if (__ballot(emit_ok && trig >= min_oplen)) {
+                // candidate ops: len >= min_oplen and I / S / D (sv_caller.cpp:566-643)
+                uint32_t cand = 0, skipped = 0, lane_skip = 0;
+                if (emit_ok) {
+                    uint32_t rpk = p0 + ro;
+#pragma unroll
+                    for (int k = 0; k < WPL; k++) {
+                        const uint32_t len = w[k] >> 4, op = w[k] & 15u;
+                        if (len >= min_oplen) {
+                            if (op == OP_I || op == OP_D) cand |= 1u << k;
+                            else if (op == OP_S) {
+                                if ((uint32_t)(rpk + 1u) >= depth_len) { skipped |= 1u << k; lane_skip += len; }
+                                else cand |= 1u << k;
+                            }
+                        }
+                        rpk += len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), w[k], 1u);
+                    }
+                }
+                uint32_t skip_before = skip_carry;
+                if (__ballot(skipped != 0)) {                 // rare: clip past the contig end (the `continue` at sv_caller.cpp:602-604)
+                    const uint32_t is = grp_incl_sum<GL>(lane_skip, upper);
+                    skip_before += is - lane_skip;
+                    skip_tot = grp_last<GL>(is);
+                }
+                if (cand) {
+                    uint32_t rpk = p0 + ro, qpk = qp, skk = skip_before;
+#pragma unroll
+                    for (int k = 0; k < WPL; k++) {
+                        const uint32_t len = w[k] >> 4, op = w[k] & 15u;
+                        if ((cand >> k) & 1u) {
+                            csv_sig sg;
+                            sg.start = rpk + 1u;
+                            sg.end = sg.start + len - 1u;
+                            sg.read = (uint32_t)r;
+                            const uint32_t kind = (op == OP_I) ? CSV_KIND_INS : (op == OP_D ? CSV_KIND_DEL : CSV_KIND_CLIP);
+                            sg.qpos_kind = ((qpk - skk) << 2) | kind;
+                            const uint32_t sl = atomicAdd(&buf_n, 1u);
+                            if (sl < SIG_BUF) buf[sl] = sg;
+                            else {
+                                const unsigned long long gi = atomicAdd(&cnt->n_sig, 1ull);
+                                if (gi < sig_cap) sig_out[gi] = sg;
+                                if (bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
+                            }
+                            my_n_del += (kind == CSV_KIND_DEL);
+                            my_overflow |= (sg.start >= start_limit);
+                        }
+                        if ((skipped >> k) & 1u) skk += len;
+                        rpk += len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), w[k], 1u);
+                        qpk += len & (uint32_t)__builtin_amdgcn_sbfe((int)(QRY_OPS | (QRY_OPS << 16)), w[k], 1u);
+                    }
+                }
+            }
+            const uint32_t ref_total = ref_carry + tot_ref, q_total = q_carry + tot_q;
+            if (last && act) {
+                // ---- the read is done: alignment interval, depth tiles it reaches
+                if (sub == 0) {
+                    uint32_t rlen = (fl & F_UNMAP) ? 0u : ref_total;      // htslib bam_endpos: pos + rlen, rlen == 0 (or unmapped) -> 1
+                    if (rlen == 0) rlen = 1;
+                    ref_end[r] = (int32_t)(p0 + rlen);
+                    q_start[r] = qs < 0 ? 0 : qs;
+                    q_end[r] = (int32_t)q_total;
+                }
+                if (tile_range && ref_total != 0 && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP))) {
+                    const uint32_t first = p0 + 1u, lastp = first + ref_total - 1u;
+                    const uint32_t t0 = first >> DEPTH_TILE_SHIFT;
+                    if (t0 < n_tiles && lastp >= first) {
+                        const uint32_t t1 = min(lastp >> DEPTH_TILE_SHIFT, n_tiles - 1u);
+                        for (uint32_t tt = t0 + sub; tt <= t1; tt += GL) {
+                            const uint32_t s = tt - tbase;
+                            if (s < TR_SLOTS) {
+                                atomicMax(&tr_first[s], ~(uint32_t)r);
+                                atomicMax(&tr_last[s], (uint32_t)r + 1u);
+                            } else {
+                                atomicMax(&tile_range[2 * (uint64_t)tt], ~(unsigned long long)r);
+                                atomicMax(&tile_range[2 * (uint64_t)tt + 1], (unsigned long long)r + 1ull);
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- advance
+            if (last) { ref_carry = 0; q_carry = 0; skip_carry = 0; qs = -1; v = 0; slot = nslot; cm = nm; act = nact; }
+            else { ref_carry = ref_total; q_carry = q_total; skip_carry += skip_tot; v = nv; }
+#pragma unroll
+            for (int k = 0; k < WPL; k++) w[k] = wn[k];
+        }
+        __builtin_amdgcn_wave_barrier();          // the table is rewritten by the next batch
+    }
+
+    // workgroup epilogue (as cigar_scan_kernel's) + the tile table
+    my_n_del = wave_sum(my_n_del);
+    const bool wave_overflow = __ballot(my_overflow != 0) != 0;
+    if (lane == 0) {
+        if (my_n_del) atomicAdd(&blk_n_del, my_n_del);
+        if (wave_overflow) atomicOr(&blk_overflow, 1u);
+    }
+    __syncthreads();
+    if (tile_range && threadIdx.x < TR_SLOTS && tr_last[threadIdx.x]) {
+        const uint64_t tt = (uint64_t)tbase + threadIdx.x;
+        atomicMax(&tile_range[2 * tt], ~(unsigned long long)(uint32_t)~tr_first[threadIdx.x]);
+        atomicMax(&tile_range[2 * tt + 1], (unsigned long long)tr_last[threadIdx.x]);
+    }
+    if (!emit) return;
+    const uint32_t nbuf = min(buf_n, SIG_BUF);
+    if (threadIdx.x == 0) {
+        blk_gbase = nbuf ? atomicAdd(&cnt->n_sig, (unsigned long long)nbuf) : 0ull;
+        if (blk_n_del) atomicAdd(&cnt->n_del, (unsigned long long)blk_n_del);
+        if (blk_overflow) cnt->max_start = 0xffffffffu;
+    }
+    __syncthreads();
+    const unsigned long long gb = blk_gbase;
+    for (uint32_t i = threadIdx.x; i < nbuf; i += RS_THREADS) {
+        const csv_sig sg = buf[i];
+        if (gb + i < sig_cap) sig_out[gb + i] = sg;
+        if (bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
+    }
+    if (bucket_hist) {
+        my_bucket_max = wave_max(my_bucket_max);
+        if (lane == 0 && my_bucket_max > BK_LOCAL_MAX) atomicMax(&cnt->max_len, my_bucket_max);
+    }
+}
+
 // Signature starts are < depth_len for coordinate-sorted input (start = pos + 1 <= contig length); the ordering pass sizes its
 // radix keys from this bound, and the scan raises ScanCounters::max_start to 0xffffffff if a start ever exceeds it.
 uint32_t scan_start_limit(uint32_t depth_len)
@@ -411,17 +704,27 @@ uint32_t scan_start_limit(uint32_t depth_len)
 
 // persistent-style grid: exactly as many workgroups as are resident at once (waves stride over the reads), so there is no partially
 // filled round of workgroups; two rounds measured best (0.177 ms; 0.191 at one round, 0.179 at three to four, 0.192 at six)
-static unsigned scan_grid(int n_cu, uint64_t n_reads)
+static unsigned scan_grid(int n_cu, uint64_t n_reads, int form)
 {
-    static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
+    static int blocks_per_cu[3] = {0, 0, 0};
+    if (blocks_per_cu[form] == 0) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_kernel, SCAN_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
-        blocks_per_cu = occ;
+        hipError_t e;
+        if (form == SCAN_FORM_WAVE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_kernel, SCAN_THREADS, 0);
+        else if (form == SCAN_FORM_ROWS16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_rows_kernel<16, true>, RS_THREADS, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_rows_kernel<8, true>, RS_THREADS, 0);
+        if (e != hipSuccess || occ <= 0) { (void)hipGetLastError(); occ = 4; }
+        blocks_per_cu[form] = occ;
     }
-    const uint64_t want = (n_reads + SCAN_WAVES - 1) / SCAN_WAVES;
-    const uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 2;
-    return (unsigned)(want < cap ? want : cap);
+    if (form == SCAN_FORM_WAVE) {
+        const uint64_t want = (n_reads + SCAN_WAVES - 1) / SCAN_WAVES;
+        const uint64_t cap = (uint64_t)n_cu * blocks_per_cu[form] * 2;
+        return (unsigned)(want < cap ? want : cap);
+    }
+    // short reads: a wave wants a few dozen reads (its groups run through them side by side); one round of workgroups while they all fit, else two
+    const uint64_t want = (n_reads + (uint64_t)RS_WAVES * RS_MIN_READS - 1) / ((uint64_t)RS_WAVES * RS_MIN_READS);
+    const uint64_t slots = (uint64_t)n_cu * blocks_per_cu[form];
+    return (unsigned)(want <= slots ? want : 2 * slots);
 }
 
 // split[2 g] = first read of wave g of launch_cigar_scan's grid, split[2 g + 1] = that read's first word, g in [0, waves]: one wave per entry, the search the scan's waves would do
@@ -435,26 +738,55 @@ __global__ __launch_bounds__(256) void scan_split_kernel(const uint64_t *__restr
     if (lane_id() == 0) { split[2 * g] = b; split[2 * g + 1] = cigar_off[b]; }
 }
 
-size_t scan_split_bytes(int n_cu, uint64_t n_reads) { return ((size_t)scan_grid(n_cu, n_reads) * SCAN_WAVES + 1) * 2 * sizeof(uint64_t); }
+// Which form of the scan (and of the depth pass's walk) suits a shard: reads of a few dozen ops (HiFi) are walked by groups of lanes,
+// several reads per wave; long reads (ONT: ~1 200 ops) by a wave each. CSV_SCAN_FORM = 0 / 1 / 2 overrides (experiments, tests).
+int scan_form_for(uint64_t n_reads, uint64_t n_cigar)
+{
+    const char *e = getenv("CSV_SCAN_FORM");
+    const int forced = e && *e ? atoi(e) : -1;
+    if (n_cigar >= 0xffffffffull) return SCAN_FORM_WAVE;          // the short-read form indexes words in 32 bits
+    if (forced >= 0 && forced <= 2) return forced;
+    return (n_reads && n_cigar / n_reads < 192) ? SCAN_FORM_ROWS16 : SCAN_FORM_WAVE;
+}
 
-void launch_scan_split(hipStream_t s, int n_cu, const csv_reads &d, uint64_t *split)
+size_t scan_split_bytes(int n_cu, uint64_t n_reads, int form)
+{
+    const size_t w = (size_t)scan_grid(n_cu, n_reads, form) * SCAN_WAVES;
+    return (w + 1) * 2 * sizeof(uint64_t);
+}
+
+void launch_scan_split(hipStream_t s, int n_cu, const csv_reads &d, uint64_t *split, int form)
 {
     if (d.n_reads == 0) return;
-    const uint64_t n_waves = (uint64_t)scan_grid(n_cu, d.n_reads) * SCAN_WAVES;
+    const uint64_t n_waves = (uint64_t)scan_grid(n_cu, d.n_reads, form) * SCAN_WAVES;
     hipLaunchKernelGGL(scan_split_kernel, dim3((unsigned)((n_waves + 1 + 3) / 4)), dim3(256), 0, s, d.cigar_off, d.n_reads, d.n_cigar, n_waves, split);
 }
 
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,
-                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &x, const uint64_t *split)
+                       int32_t *ref_end, int32_t *q_start, int32_t *q_end, uint32_t *ckpt, ScanCounters *cnt, const ScanExtras &x, const uint64_t *split,
+                       int form, uint32_t cigar_pad_words)
 {
     if (d.n_reads == 0) return;
-    const unsigned grid = scan_grid(n_cu, d.n_reads);
+    static_assert(SCAN_WAVES == RS_WAVES, "one split table layout for both forms");
+    if (form != SCAN_FORM_WAVE && d.n_cigar >= 0xffffffffull) { form = SCAN_FORM_WAVE; split = nullptr; }
+    const unsigned grid = scan_grid(n_cu, d.n_reads, form);
     const int vec_ok = (((uintptr_t)d.cigar) & 15u) == 0;
-    hipLaunchKernelGGL(cigar_scan_kernel, dim3(grid), dim3(SCAN_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
-                       d.mapq, d.cigar_off, d.cigar, vec_ok, depth_len, scan_start_limit(depth_len), min_oplen, min_mapq, emit, sig_out, sig_cap,
-                       ref_end, q_start, q_end, ckpt, cnt, (unsigned long long *)x.tile_range, x.n_tiles, emit ? x.bucket_hist : nullptr, x.type_pos, x.bucket_shift,
-                       split);
+    if (form == SCAN_FORM_WAVE) {
+        hipLaunchKernelGGL(cigar_scan_kernel, dim3(grid), dim3(SCAN_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag,
+                           d.mapq, d.cigar_off, d.cigar, vec_ok, depth_len, scan_start_limit(depth_len), min_oplen, min_mapq, emit, sig_out, sig_cap,
+                           ref_end, q_start, q_end, ckpt, cnt, (unsigned long long *)x.tile_range, x.n_tiles, emit ? x.bucket_hist : nullptr, x.type_pos, x.bucket_shift,
+                           split);
+        return;
+    }
+    const bool padded = vec_ok && cigar_pad_words >= 128;
+#define CSV_ROWS_LAUNCH(GL, PAD)                                                                                                                       \
+    hipLaunchKernelGGL((cigar_scan_rows_kernel<GL, PAD>), dim3(grid), dim3(RS_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag, d.mapq, d.cigar_off,   \
+                       d.cigar, depth_len, scan_start_limit(depth_len), min_oplen, min_mapq, emit, sig_out, sig_cap, ref_end, q_start, q_end, ckpt, cnt,  \
+                       (unsigned long long *)x.tile_range, x.n_tiles, emit ? x.bucket_hist : nullptr, x.type_pos, x.bucket_shift, split)
+    if (form == SCAN_FORM_ROWS16) { if (padded) CSV_ROWS_LAUNCH(16, true); else CSV_ROWS_LAUNCH(16, false); }
+    else { if (padded) CSV_ROWS_LAUNCH(8, true); else CSV_ROWS_LAUNCH(8, false); }
+#undef CSV_ROWS_LAUNCH
 }
 
 // cigar_off of arrays that already live in HBM (csvgpu_shard_wrap_dev) gets the test the host arrays get in check_reads
