@@ -588,11 +588,43 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     tot = wave_total_dpp(tot);
     if (lane == 0) wave_tot[wave] = tot;
     __syncthreads();
-    uint32_t carry = 0;
-    for (int w = 0; w < wave; w++) carry += wave_tot[w];
+    // prefix of the waves' totals: lanes 0..15 scan them (one DPP row), the wave reads its predecessor's
+    static_assert(DEPTH_WAVES == 16, "the waves' totals are scanned by one DPP row");
+    uint32_t carry;
+    {
+        uint32_t wt = lane < DEPTH_WAVES ? wave_tot[lane] : 0u;
+        wt += dpp_u32<0x111, 0xf>(0u, wt); wt += dpp_u32<0x112, 0xf>(0u, wt); wt += dpp_u32<0x114, 0xf>(0u, wt); wt += dpp_u32<0x118, 0xf>(0u, wt);
+        const int wv = (int)uniform32((uint32_t)wave);
+        carry = wv ? (uint32_t)__builtin_amdgcn_readlane((int)wt, wv - 1) : 0u;
+    }
 
     uint64_t my_sum = 0;
     uint32_t my_nz = 0;
+    // A whole tile with an aligned output: no per-position bound tests, one 16-byte store per lane and round at a constant offset from one
+    // address, the tile's sum in 32-bit partial sums — a position's depth is at most the tile's candidate count (a read covers a position
+    // once), so 16 values per lane and 64 lanes stay below 2^32 while there are fewer than 2^20 candidates —, non-zero counts on the scalar
+    // unit (ballot + popcount). The scan + write-out was 400 of a wave's ~600 (HiFi) / ~2 500 (ONT) vector instructions per tile.
+    const bool fast = depth && dvec_ok && (T1 - T0) == (uint64_t)DEPTH_TILE && (k_hi - k_lo) < (1ull << 20);
+    if (fast) {
+        uint32_t *__restrict__ const dptr = depth + T0 + (uint64_t)(w_base + lane * 4);
+        uint32_t s32 = 0, nzs = 0;
+#pragma unroll
+        for (int rd = 0; rd < DEPTH_ROUNDS; rd++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&diff[w_base + rd * 4 * WAVE + lane * 4]);
+            const uint32_t l0 = v.x, l1 = l0 + v.y, l2 = l1 + v.z, l3 = l2 + v.w;
+            const uint32_t incl = wave_incl_sum_dpp(l3);
+            const uint32_t pre = carry + (incl - l3);
+            uint4 d;
+            d.x = pre + l0; d.y = pre + l1; d.z = pre + l2; d.w = pre + l3;
+            *reinterpret_cast<uint4 *>(dptr + rd * 4 * WAVE) = d;
+            s32 += (d.x + d.y) + (d.z + d.w);
+            nzs += (uint32_t)__popcll(__ballot(d.x != 0)) + (uint32_t)__popcll(__ballot(d.y != 0)) + (uint32_t)__popcll(__ballot(d.z != 0)) +
+                   (uint32_t)__popcll(__ballot(d.w != 0));
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        const uint32_t tot32 = wave_total_dpp(s32);
+        if (lane == 0) { atomicAdd(&blk_sum, (unsigned long long)tot32); atomicAdd(&blk_nz, nzs); }
+    } else {
 #pragma unroll
     for (int rd = 0; rd < DEPTH_ROUNDS; rd++) {
         const int off = w_base + rd * 4 * WAVE + lane * 4;
@@ -622,6 +654,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     my_sum = wave_sum64(my_sum);
     my_nz = wave_sum(my_nz);
     if (lane == 0) { atomicAdd(&blk_sum, (unsigned long long)my_sum); atomicAdd(&blk_nz, my_nz); }
+    }
     __syncthreads();
     PHASE_MARK(4);
     if (threadIdx.x == 0) {

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(SCAN_THREADS, SCAN_OCC) void cigar_scan_kernel(
 // 60x every tile is reached by a hundred reads: two same-address device atomics per (read, tile) otherwise).
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / WAVE;
-constexpr int rs_occ(int gl) { return gl == 8 ? 5 : 8; }    // workgroups per CU the registers allow (8 words per lane and their prefetch: 96 registers)
+constexpr int rs_occ(int gl) { return gl == 8 ? 5 : 7; }    // workgroups per CU the registers allow (8 words per lane and their prefetch: 96 registers)
 constexpr uint32_t TR_SLOTS = 64;            // depth tiles (from the workgroup's first read's tile on) whose ranges are combined in LDS
 constexpr uint32_t RS_MIN_READS = 32;        // reads per wave below which the grid shrinks instead
 
@@ -485,6 +485,7 @@ __global__ __launch_bounds__(RS_THREADS, rs_occ(GL)) void cigar_scan_rows_kernel
 
     for (uint64_t rb = r_begin; rb < r_end; rb += WAVE) {
         const uint32_t nb = (uint32_t)min((uint64_t)WAVE, r_end - rb);
+        uint32_t l_p0 = 0, l_fl = 0;      // lane l: pos and flag of read rb + l (for the batch's write-out)
         {   // the batch's metadata, lane-parallel and coalesced
             uint4 m = make_uint4(0u, 0u, 0u, 0u);
             uint32_t l_uns = 0;
@@ -493,6 +494,7 @@ __global__ __launch_bounds__(RS_THREADS, rs_occ(GL)) void cigar_scan_rows_kernel
                 const uint64_t c0 = cigar_off[rr], c1 = cigar_off[rr + 1];
                 const int32_t p = pos[rr];
                 m = make_uint4((uint32_t)c0, (uint32_t)(c1 - c0), (uint32_t)p, (uint32_t)flag[rr] | ((uint32_t)mapq[rr] << 16));
+                l_p0 = m.z; l_fl = m.w & 0xffffu;
                 l_uns = (rr > 0 && p < pos[rr - 1]) ? 1u : 0u;
             }
             if (__ballot(l_uns != 0) && lane == 0) cnt->unsorted = 1u;
@@ -526,7 +528,6 @@ __global__ __launch_bounds__(RS_THREADS, rs_occ(GL)) void cigar_scan_rows_kernel
             loadw(nact ? (nm.x & ~3u) + nv * 64u + sub * WPL : 0u, wn);
 
             // ---- window v of the current read ------------------------------------------------------------------------
-            const uint64_t r = rb + slot;
             const uint32_t g = a + v * 64u + sub * WPL;                  // this lane's first word
             const uint32_t t = g - c0;                                   // ... relative to the read's first word (wraps in front of it)
             // sv_caller.cpp:526
@@ -572,25 +573,27 @@ __global__ __launch_bounds__(RS_THREADS, rs_occ(GL)) void cigar_scan_rows_kernel
             }
             uint32_t skip_tot = 0;
             if (__ballot(emit_ok && trig >= min_oplen)) {
-                // candidate ops: len >= min_oplen and I / S / D (sv_caller.cpp:566-643)
-                uint32_t cand = 0, skipped = 0, lane_skip = 0;
+                // candidate ops: len >= min_oplen and I / S / D (sv_caller.cpp:566-643). A soft clip whose position is at or beyond the contig's
+                // end is skipped there together with its cursor update (the `continue` at :602-604); no op of this window can be one while
+                // even the window's last cursor stays in front of the end — the ordinary case, which then needs no cursor per word.
+                constexpr uint32_t ISD_OPS = (1u << OP_I) | (1u << OP_S) | (1u << OP_D);
+                uint32_t cand = 0, skipped = 0;
                 if (emit_ok) {
-                    uint32_t rpk = p0 + ro;
+#pragma unroll
+                    for (int k = 0; k < WPL; k++)
+                        if ((w[k] >> 4) >= min_oplen && __builtin_amdgcn_sbfe((int)(ISD_OPS | (ISD_OPS << 16)), w[k], 1u)) cand |= 1u << k;
+                }
+                const bool may_skip = ((p0 | ref_carry | tot_ref) >= 0x20000000u) || (p0 + ref_carry + tot_ref + 1u >= depth_len);
+                uint32_t skip_before = skip_carry;
+                if (__ballot(cand != 0 && may_skip)) {         // rare: a read that reaches the contig's end (or absurd coordinates)
+                    uint32_t lane_skip = 0, rpk = p0 + ro;
 #pragma unroll
                     for (int k = 0; k < WPL; k++) {
                         const uint32_t len = w[k] >> 4, op = w[k] & 15u;
-                        if (len >= min_oplen) {
-                            if (op == OP_I || op == OP_D) cand |= 1u << k;
-                            else if (op == OP_S) {
-                                if ((uint32_t)(rpk + 1u) >= depth_len) { skipped |= 1u << k; lane_skip += len; }
-                                else cand |= 1u << k;
-                            }
-                        }
+                        if (((cand >> k) & 1u) && op == OP_S && (uint32_t)(rpk + 1u) >= depth_len) { skipped |= 1u << k; lane_skip += len; }
                         rpk += len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), w[k], 1u);
                     }
-                }
-                uint32_t skip_before = skip_carry;
-                if (__ballot(skipped != 0)) {                 // rare: clip past the contig end (the `continue` at sv_caller.cpp:602-604)
+                    cand &= ~skipped;
                     const uint32_t is = grp_incl_sum<GL>(lane_skip, upper);
                     skip_before += is - lane_skip;
                     skip_tot = grp_last<GL>(is);
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(RS_THREADS, rs_occ(GL)) void cigar_scan_rows_kernel
                             csv_sig sg;
                             sg.start = rpk + 1u;
                             sg.end = sg.start + len - 1u;
-                            sg.read = (uint32_t)r;
+                            sg.read = (uint32_t)rb + slot;
                             const uint32_t kind = (op == OP_I) ? CSV_KIND_INS : (op == OP_D ? CSV_KIND_DEL : CSV_KIND_CLIP);
                             sg.qpos_kind = ((qpk - skk) << 2) | kind;
                             const uint32_t sl = atomicAdd(&buf_n, 1u);
@@ -624,39 +627,55 @@ __global__ __launch_bounds__(RS_THREADS, rs_occ(GL)) void cigar_scan_rows_kernel
                 }
             }
             const uint32_t ref_total = ref_carry + tot_ref, q_total = q_carry + tot_q;
-            if (last && act) {
-                // ---- the read is done: alignment interval, depth tiles it reaches
-                if (sub == 0) {
-                    uint32_t rlen = (fl & F_UNMAP) ? 0u : ref_total;      // htslib bam_endpos: pos + rlen, rlen == 0 (or unmapped) -> 1
-                    if (rlen == 0) rlen = 1;
-                    ref_end[r] = (int32_t)(p0 + rlen);
-                    q_start[r] = qs < 0 ? 0 : qs;
-                    q_end[r] = (int32_t)q_total;
-                }
-                if (tile_range && ref_total != 0 && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP))) {
-                    const uint32_t first = p0 + 1u, lastp = first + ref_total - 1u;
-                    const uint32_t t0 = first >> DEPTH_TILE_SHIFT;
-                    if (t0 < n_tiles && lastp >= first) {
-                        const uint32_t t1 = min(lastp >> DEPTH_TILE_SHIFT, n_tiles - 1u);
-                        for (uint32_t tt = t0 + sub; tt <= t1; tt += GL) {
-                            const uint32_t s = tt - tbase;
-                            if (s < TR_SLOTS) {
-                                atomicMax(&tr_first[s], ~(uint32_t)r);
-                                atomicMax(&tr_last[s], (uint32_t)r + 1u);
-                            } else {
-                                atomicMax(&tile_range[2 * (uint64_t)tt], ~(unsigned long long)r);
-                                atomicMax(&tile_range[2 * (uint64_t)tt + 1], (unsigned long long)r + 1ull);
-                            }
-                        }
-                    }
-                }
-            }
+            // the read is done: its totals take its place in the table (written out for the whole batch below)
+            if (last && act && sub == 0) meta[wave][slot] = make_uint4(ref_total, (uint32_t)qs, q_total, 0u);
             // ---- advance
             if (last) { ref_carry = 0; q_carry = 0; skip_carry = 0; qs = -1; v = 0; slot = nslot; cm = nm; act = nact; }
             else { ref_carry = ref_total; q_carry = q_total; skip_carry += skip_tot; v = nv; }
 #pragma unroll
             for (int k = 0; k < WPL; k++) w[k] = wn[k];
         }
+        // ---- the batch is done: alignment intervals and the depth tiles each read reaches, lane l <-> read rb + l again (coalesced stores;
+        // once per 64 reads instead of once per read)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const bool mine = (uint32_t)lane < nb;
+            const uint4 res = meta[wave][lane];                       // {reference bases, query_start or -1, query bases}
+            const uint64_t rr = rb + lane;
+            if (mine) {
+                uint32_t rlen = (l_fl & F_UNMAP) ? 0u : res.x;        // htslib bam_endpos: pos + rlen, rlen == 0 (or unmapped) -> 1
+                if (rlen == 0) rlen = 1;
+                ref_end[rr] = (int32_t)(l_p0 + rlen);
+                q_start[rr] = (int32_t)res.y < 0 ? 0 : (int32_t)res.y;
+                q_end[rr] = (int32_t)res.z;
+            }
+            // depth tiles (ScanExtras::tile_range): same filter as the depth pass (cnv_caller.cpp:491-495), positions in uint32 as there
+            uint32_t t0 = 1, t1 = 0;
+            if (mine && tile_range && res.x != 0 && !(l_fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP))) {
+                const uint32_t first = l_p0 + 1u, lastp = first + res.x - 1u;
+                if ((first >> DEPTH_TILE_SHIFT) < n_tiles && lastp >= first) { t0 = first >> DEPTH_TILE_SHIFT; t1 = min(lastp >> DEPTH_TILE_SHIFT, n_tiles - 1u); }
+            }
+            auto mark = [&](uint32_t tt, uint32_t rd) {
+                const uint32_t sl = tt - tbase;
+                if (sl < TR_SLOTS) {
+                    atomicMax(&tr_first[sl], ~rd);
+                    atomicMax(&tr_last[sl], rd + 1u);
+                } else {
+                    atomicMax(&tile_range[2 * (uint64_t)tt], ~(unsigned long long)rd);
+                    atomicMax(&tile_range[2 * (uint64_t)tt + 1], (unsigned long long)rd + 1ull);
+                }
+            };
+            const bool wide = t1 >= t0 && t1 - t0 >= 8u;              // a read across many tiles (long skips): the whole wave marks them
+            if (t1 >= t0 && !wide) for (uint32_t tt = t0; tt <= t1; tt++) mark(tt, (uint32_t)rr);
+            for (uint64_t mw = __ballot(wide); mw; mw &= mw - 1) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(mw);
+                const uint32_t a0 = bcast32(t0, src), a1 = bcast32(t1, src), rd = (uint32_t)rb + src;
+                for (uint32_t tt = a0 + (uint32_t)lane; tt <= a1; tt += WAVE) mark(tt, rd);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();          // the table is rewritten by the next batch
     }
 
