@@ -250,6 +250,27 @@ void launch_so_keys(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_
 void launch_so_setlist(hipStream_t s, const SplitOrderTab &tab, uint64_t M, const uint32_t *vals, uint32_t *list);
 void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nodes, const uint64_t *node_hash, const uint32_t *node_rec, const uint32_t *list,
                          const uint64_t *supp_hash, uint64_t n_supp, csv_split_survivor *out, uint64_t cap, unsigned long long *count);
+// the last epochs for the survivors only (splitorder.hip): level j = the contig's last epoch minus j
+constexpr uint32_t SO_TAIL_MAX = 3;
+struct SplitTailHost {
+    uint32_t A = 0, D = 0;
+    int      wv = 0, wa = 0;
+    uint32_t nbase[SO_MAX_CONTIGS + 1] = {0};
+    uint32_t B[SO_TAIL_MAX][SO_MAX_CONTIGS] = {{0}};
+    uint32_t F[SO_TAIL_MAX][SO_MAX_CONTIGS] = {{0}};
+    uint32_t boff[SO_TAIL_MAX][SO_MAX_CONTIGS + 1] = {{0}};
+};
+void launch_st_survivors(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, const uint64_t *node_hash, const uint64_t *supp_hash, uint64_t n_supp, uint8_t *is_surv,
+                         uint32_t *bitmap);
+void launch_st_member(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, int j, const uint64_t *node_hash, const uint32_t *bitmap_prev, uint32_t *bitmap_next,
+                      uint32_t *set, unsigned int *count);
+void launch_st_inverse(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, int j_last, const uint32_t *list, uint32_t *prevrank);
+void launch_st_mint(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint64_t *node_hash, const uint32_t *prevrank, uint32_t *minT);
+void launch_st_keys(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint64_t *node_hash, const uint32_t *prevrank, const uint32_t *minT,
+                    uint64_t *keys, uint32_t *vals);
+void launch_st_rank(hipStream_t s, const uint32_t *vals, uint32_t n, uint32_t *prevrank);
+void launch_st_emit(hipStream_t s, const SplitTailHost &h, const uint32_t *vals, uint32_t n, const uint8_t *is_surv, const uint32_t *node_rec, csv_split_survivor *out,
+                    uint64_t cap, unsigned long long *count);
 // dbscan1d.hip
 void launch_dbscan_1d_batched(hipStream_t s, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg,
                               double eps, int min_pts, int32_t *labels, unsigned int *too_large_flag);

@@ -1113,23 +1113,88 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
     // ---- the chain of epochs: a contig takes part in epoch k while it still has nodes inserted at or after the epoch's first node ----
     std::vector<uint64_t> first_node, buckets;
     split_order_epochs(n_max, first_node, buckets);
-    uint64_t scratch = 0;
+    // The last D epochs of every contig are ordered for the survivors (and the nodes their order depends on) only: splitorder.hip.
+    // The sets double per level and the epochs halve, so D levels pay while 4^D <= nodes per supplementary record.
+    int D = 0;
+    {
+        const uint64_t ratio = n_nodes / std::max<uint64_t>(n_supp, 1);
+        while (D < (int)SO_TAIL_MAX && (ratio >> (2 * (D + 1))) >= 1) D++;
+        const char *e = getenv("CSV_SPLIT_TAIL");
+        if (e && *e) D = std::min<int>(std::max(atoi(e), 0), (int)SO_TAIL_MAX);
+    }
+    SplitTailHost th;
+    th.A = (uint32_t)n_contigs; th.wv = std::max(1, bits_of(n_nodes)); th.wa = std::max(1, bits_of((uint64_t)n_contigs - 1));
+    if (n_nodes >= (1ull << 31) || th.wa + 2 * (th.wv + 1) > 64) D = 0;
+    th.D = (uint32_t)D;
+    std::vector<int> K((size_t)n_contigs, -1);                       // a contig's last epoch
+    for (int c = 0; c < n_contigs; c++) {
+        for (size_t k = 0; k < first_node.size() && N[(size_t)c] > first_node[k]; k++) K[(size_t)c] = (int)k;
+        th.nbase[c] = tab.nbase[c];
+    }
+    th.nbase[n_contigs] = (uint32_t)n_nodes;
+    uint64_t tail_buckets = 0;
+    for (int j = 0; j < D; j++) {
+        uint64_t off = 0;
+        for (int c = 0; c < n_contigs; c++) {
+            const int e = K[(size_t)c] - j;
+            th.B[j][c] = e >= 0 ? (uint32_t)buckets[(size_t)e] : 1u;
+            th.F[j][c] = e >= 0 ? (uint32_t)first_node[(size_t)e] : 0u;
+            th.boff[j][c] = (uint32_t)off;
+            off += th.B[j][c];
+        }
+        if (off >= 0xffffffe0ull) { D = 0; th.D = 0; break; }
+        for (int c = n_contigs; c <= (int)SO_MAX_CONTIGS; c++) th.boff[j][c] = (uint32_t)off;
+        tail_buckets = std::max(tail_buckets, off);
+    }
+    auto in_chain = [&](int c, size_t k) { return N[(size_t)c] > first_node[k] && (int)k <= K[(size_t)c] - D; };
+    uint64_t scratch = tail_buckets * 4;
     for (size_t k = 0; k < first_node.size(); k++) {
         uint64_t A = 0;
-        for (int c = 0; c < n_contigs; c++) A += N[(size_t)c] > first_node[k];
+        for (int c = 0; c < n_contigs; c++) A += in_chain(c, k);
         scratch = std::max(scratch, A * buckets[k] * 4);
     }
-    if ((rc = arena_reserve(ctx, ctx->work, align_up(scratch, 256) + sortws_bytes(n_nodes) + align_up(n_nodes * sizeof(csv_split_survivor), 256) + 4096))) return rc;
+    const size_t bm_words = (size_t)((tail_buckets + 31) / 32 + 8);
+    if ((rc = arena_reserve(ctx, ctx->work, align_up(scratch + 16, 256) + sortws_bytes(n_nodes) + align_up(n_nodes * sizeof(csv_split_survivor), 256) +
+                                                (size_t)D * (align_up(bm_words * 4, 256) + align_up(n_nodes * 4, 256)) + align_up(n_nodes, 256) + align_up(n_nodes * 4, 256) + 8192))) return rc;
     uint32_t *minT = (uint32_t *)arena_alloc(ctx->work, scratch + 16);
     SortWs w;
     if (!minT || !sortws_carve(ctx->work, n_nodes, w)) { ctx->err = "arena exhausted (split order epochs)"; return CSV_ENOMEM; }
+    const uint64_t cap = n_nodes;
+    csv_split_survivor *d_out = (csv_split_survivor *)arena_alloc(ctx->work, cap * sizeof(csv_split_survivor));
+    unsigned long long *d_count = (unsigned long long *)arena_alloc(ctx->work, 256);      // [0] survivors; 32-bit set sizes from byte 64 on
+    if (!d_out || !d_count) { ctx->err = "arena exhausted (split order survivors)"; return CSV_ENOMEM; }
+    CSV_HIP(ctx, hipMemsetAsync(d_count, 0, 256, s));
+    unsigned int *d_setn = (unsigned int *)((char *)d_count + 64);
+
+    // ---- top-down: who takes part in the last D epochs (hashes only; needs nothing of the chain) ----
+    uint32_t *bitmap[SO_TAIL_MAX] = {nullptr, nullptr, nullptr}, *set[SO_TAIL_MAX + 1] = {nullptr, nullptr, nullptr, nullptr}, *prevrank = nullptr;
+    uint8_t *is_surv = nullptr;
+    uint32_t set_n[SO_TAIL_MAX + 1] = {0, 0, 0, 0};
+    if (D > 0) {
+        for (int j = 0; j < D; j++) {
+            bitmap[j] = (uint32_t *)arena_alloc(ctx->work, bm_words * 4);
+            set[j + 1] = (uint32_t *)arena_alloc(ctx->work, n_nodes * 4);
+            if (!bitmap[j] || !set[j + 1]) { ctx->err = "arena exhausted (split order tail)"; return CSV_ENOMEM; }
+            CSV_HIP(ctx, hipMemsetAsync(bitmap[j], 0, bm_words * 4, s));
+        }
+        is_surv = (uint8_t *)arena_alloc(ctx->work, n_nodes);
+        prevrank = (uint32_t *)arena_alloc(ctx->work, n_nodes * 4);
+        if (!is_surv || !prevrank) { ctx->err = "arena exhausted (split order tail)"; return CSV_ENOMEM; }
+        launch_st_survivors(s, th, (uint32_t)n_nodes, node_hash, d_supp, n_supp, is_surv, bitmap[0]);
+        for (int j = 1; j <= D; j++)
+            launch_st_member(s, th, (uint32_t)n_nodes, j, node_hash, bitmap[j - 1], j < D ? bitmap[j] : nullptr, set[j], d_setn + j);
+        CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_setn, 16, hipMemcpyDeviceToHost, s));
+        CSV_HIP(ctx, wait_stream(s));
+        for (int j = 1; j <= D; j++) set_n[j] = ((const uint32_t *)ctx->pinned)[j];
+    }
+
     for (size_t k = 0; k < first_node.size(); k++) {
         SplitOrderTab e;
         e.A = 0;
         uint64_t M = 0, m_max = 0;
         const uint64_t next_first = k + 1 < first_node.size() ? first_node[k + 1] : ~0ull;
         for (int c = 0; c < n_contigs; c++) {
-            if (N[(size_t)c] <= first_node[k]) continue;
+            if (!in_chain(c, k)) continue;
             const uint64_t m = std::min(N[(size_t)c], next_first);                 // nodes present at the end of this epoch
             e.work_off[e.A] = M; e.nbase[e.A] = tab.nbase[c]; e.m_old[e.A] = (uint32_t)first_node[k];
             e.A++; M += m; m_max = std::max(m_max, m);
@@ -1148,13 +1213,25 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         launch_so_setlist(s, e, M, io ? w.v1 : w.v0, list);
     }
 
-    // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
-    const uint64_t cap = n_nodes;
-    csv_split_survivor *d_out = (csv_split_survivor *)arena_alloc(ctx->work, cap * sizeof(csv_split_survivor));
-    unsigned long long *d_count = (unsigned long long *)arena_alloc(ctx->work, 256);
-    if (!d_out || !d_count) { ctx->err = "arena exhausted (split order survivors)"; return CSV_ENOMEM; }
-    CSV_HIP(ctx, hipMemsetAsync(d_count, 0, 8, s));
-    launch_so_survivors(s, tab, n_nodes, node_hash, node_rec, list, d_supp, n_supp, d_out, cap, d_count);
+    if (D == 0) {
+        // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
+        launch_so_survivors(s, tab, n_nodes, node_hash, node_rec, list, d_supp, n_supp, d_out, cap, d_count);
+    } else {
+        // ---- bottom-up: order S_D with the chain's positions, then each smaller set with the ranks of the order before ----
+        launch_st_inverse(s, th, (uint32_t)n_nodes, D - 1, list, prevrank);
+        const int key_bits = th.wa + 2 * (th.wv + 1);
+        for (int j = D - 1; j >= 0; j--) {
+            const uint32_t n = set_n[j + 1];
+            if (n == 0) continue;
+            CSV_HIP(ctx, hipMemsetAsync(minT, 0xff, (size_t)th.boff[j][n_contigs] * 4, s));
+            launch_st_mint(s, th, j, set[j + 1], n, node_hash, prevrank, minT);
+            launch_st_keys(s, th, j, set[j + 1], n, node_hash, prevrank, minT, w.k0, w.v0);
+            const int io = launch_radix_sort_u64(s, w.k0, w.v0, w.k1, w.v1, n, key_bits, w.tmp);
+            const uint32_t *sorted = n > 1 ? (io ? w.v1 : w.v0) : w.v0;
+            if (j > 0) launch_st_rank(s, sorted, n, prevrank);
+            else launch_st_emit(s, th, sorted, n, is_surv, node_rec, d_out, cap, d_count);
+        }
+    }
     CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_count, 8, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, wait_stream(s));
     const uint64_t n_surv = *(const unsigned long long *)ctx->pinned;

@@ -154,6 +154,158 @@ __global__ __launch_bounds__(SO_THREADS) void so_survivors_kernel(SplitOrderTab 
     if (slot < cap) out[slot] = csv_split_survivor{a, p, node_rec[g]};
 }
 
+// ---- the last epochs, survivors only ---------------------------------------------------------------------------------------------------
+// Half of the chain's work is its last epoch, three quarters its last two — and all the caller wants is the relative order of the ~1 % of
+// nodes that survive the erase. The order at the end of an epoch is by (min t of the node's bucket, t), so the order among a SET of nodes
+// needs the t of the set's members and of every node that shares a bucket with one of them, nothing else; and t is only ever COMPARED, so
+// for the nodes that were in the list when the epoch began any order-preserving number will do in place of the list position. Hence, for
+// the last D epochs e = K, K-1, ... of every contig (K its last epoch; level j = K - e):
+//   top-down (hashes only):  S_1 = the nodes that share an epoch-K bucket with a survivor; S_2 = the nodes that were in the list when epoch K
+//            began and share an epoch-(K-1) bucket with such a member of S_1; ... Each step streams the epoch's nodes past a bitmap of marked
+//            buckets (2 N bits: resident in L2) — sequential reads and a 64-bit modulo, no sort, no scattered atomics. The sets double per
+//            level while the epochs halve: D = 3 for 1 % survivors.
+//   bottom-up:  the chain of full sorts runs only up to epoch K - D (an eighth of its keys); then level D-1 orders S_D with t = list position
+//            (old nodes: the chain's result) or insertion index (new nodes, flag bit above), level D-2 orders S_(D-1) with t = rank in the
+//            order just computed, ..., level 0 orders S_1 and the survivors leave in that order.
+struct SplitTailTab {                        // passed by value
+    uint32_t A = 0, D = 0;
+    int      wv = 0;                         // bits of a t value (the new-node flag sits above them)
+    int      wa = 0;                         // bits of a contig index
+    uint32_t nbase[SO_MAX_CONTIGS + 1];
+    uint32_t B[SO_TAIL_MAX][SO_MAX_CONTIGS];           // bucket count of epoch K_c - j (1 where the contig has no such epoch)
+    uint32_t F[SO_TAIL_MAX][SO_MAX_CONTIGS];           // first node inserted in that epoch = nodes in the list when it began (0 where no such epoch)
+    uint32_t boff[SO_TAIL_MAX][SO_MAX_CONTIGS + 1];    // first bucket of contig c in level j's bucket tables (bitmap bits; minT entries)
+};
+
+__device__ __forceinline__ uint32_t tail_owner(const SplitTailTab &t, uint32_t g)
+{
+    uint32_t a = 0;
+    for (uint32_t k = 1; k < t.A; k++) a += (g >= t.nbase[k]);
+    return a;
+}
+
+// one atomic per wave reserves the slots of its appending lanes
+__device__ __forceinline__ uint32_t wave_append(bool p, unsigned int *counter)
+{
+    const uint64_t m = __ballot(p);
+    if (!m) return 0;
+    uint32_t base = 0;
+    if (lane_id() == (int)__builtin_ctzll(m)) base = atomicAdd(counter, (unsigned int)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+    return base + (uint32_t)__popcll(m & lanemask_lt());
+}
+
+// level 0 of the top-down pass: the survivors (name hash among the supplementary records') mark their epoch-K buckets
+__global__ __launch_bounds__(SO_THREADS) void st_survivors_kernel(SplitTailTab tab, uint32_t n_nodes, const uint64_t *__restrict__ node_hash,
+                                                                  const uint64_t *__restrict__ supp_hash, uint64_t n_supp, uint8_t *__restrict__ is_surv,
+                                                                  uint32_t *__restrict__ bitmap)
+{
+    const uint32_t g = blockIdx.x * SO_THREADS + threadIdx.x;
+    if (g >= n_nodes) return;
+    const uint64_t h = node_hash[g];
+    uint64_t lo = 0, hi = n_supp;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (supp_hash[mid] < h) lo = mid + 1; else hi = mid; }
+    const bool sv = lo < n_supp && supp_hash[lo] == h;
+    is_surv[g] = sv ? 1 : 0;
+    if (sv) {
+        const uint32_t a = tail_owner(tab, g);
+        const uint32_t b = tab.boff[0][a] + (uint32_t)(h % (uint64_t)tab.B[0][a]);
+        atomicOr(&bitmap[b >> 5], 1u << (b & 31u));
+    }
+}
+
+// level j >= 1: the nodes present at the end of epoch K - (j - 1) whose bucket there is marked form S_j; those of them that were already in
+// the list when that epoch began mark their bucket of the epoch before (unless this is the last level)
+__global__ __launch_bounds__(SO_THREADS) void st_member_kernel(SplitTailTab tab, uint32_t n_nodes, int j, const uint64_t *__restrict__ node_hash,
+                                                               const uint32_t *__restrict__ bitmap_prev, uint32_t *__restrict__ bitmap_next,
+                                                               uint32_t *__restrict__ set, unsigned int *__restrict__ count)
+{
+    const uint32_t g = blockIdx.x * SO_THREADS + threadIdx.x;
+    bool in = false;
+    uint32_t a = 0, x = 0;
+    uint64_t h = 0;
+    if (g < n_nodes) {
+        a = tail_owner(tab, g);
+        x = g - tab.nbase[a];
+        const uint32_t lim = j == 1 ? tab.nbase[a + 1] - tab.nbase[a] : tab.F[j - 2][a];        // nodes present at the end of epoch K - (j - 1)
+        if (x < lim) {
+            h = node_hash[g];
+            const uint32_t b = tab.boff[j - 1][a] + (uint32_t)(h % (uint64_t)tab.B[j - 1][a]);
+            in = (bitmap_prev[b >> 5] >> (b & 31u)) & 1u;
+        }
+    }
+    const uint32_t slot = wave_append(in, count);
+    if (in) {
+        set[slot] = g;
+        if (bitmap_next && x < tab.F[j - 1][a]) {
+            const uint32_t b = tab.boff[j][a] + (uint32_t)(h % (uint64_t)tab.B[j][a]);
+            atomicOr(&bitmap_next[b >> 5], 1u << (b & 31u));
+        }
+    }
+}
+
+// the chain's result as node -> list position
+__global__ __launch_bounds__(SO_THREADS) void st_inverse_kernel(SplitTailTab tab, uint32_t n_nodes, int j_last, const uint32_t *__restrict__ list,
+                                                                uint32_t *__restrict__ prevrank)
+{
+    const uint32_t g = blockIdx.x * SO_THREADS + threadIdx.x;
+    if (g >= n_nodes) return;
+    const uint32_t a = tail_owner(tab, g);
+    const uint32_t p = g - tab.nbase[a];
+    const uint32_t m = tab.F[j_last][a];                              // nodes the chain ordered for this contig
+    if (p >= m) return;
+    prevrank[tab.nbase[a] + (m > 1 ? list[g] : 0u)] = p;
+}
+
+// level j, bottom-up: t of every member of S_(j+1) at epoch K - j and the minimum per bucket
+__device__ __forceinline__ uint32_t st_t(const SplitTailTab &tab, int j, uint32_t a, uint32_t x, uint32_t g, const uint32_t *__restrict__ prevrank)
+{
+    return x < tab.F[j][a] ? prevrank[g] : ((1u << tab.wv) | x);
+}
+__global__ __launch_bounds__(SO_THREADS) void st_mint_kernel(SplitTailTab tab, int j, const uint32_t *__restrict__ set, uint32_t n, const uint64_t *__restrict__ node_hash,
+                                                             const uint32_t *__restrict__ prevrank, uint32_t *__restrict__ minT)
+{
+    const uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = set[i];
+    const uint32_t a = tail_owner(tab, g);
+    const uint32_t b = tab.boff[j][a] + (uint32_t)(node_hash[g] % (uint64_t)tab.B[j][a]);
+    atomicMin(&minT[b], st_t(tab, j, a, g - tab.nbase[a], g, prevrank));
+}
+__global__ __launch_bounds__(SO_THREADS) void st_keys_kernel(SplitTailTab tab, int j, const uint32_t *__restrict__ set, uint32_t n, const uint64_t *__restrict__ node_hash,
+                                                             const uint32_t *__restrict__ prevrank, const uint32_t *__restrict__ minT,
+                                                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = set[i];
+    const uint32_t a = tail_owner(tab, g);
+    const uint32_t b = tab.boff[j][a] + (uint32_t)(node_hash[g] % (uint64_t)tab.B[j][a]);
+    const uint32_t t = st_t(tab, j, a, g - tab.nbase[a], g, prevrank);
+    const int w = tab.wv + 1;
+    const uint64_t mask = (1ull << w) - 1ull;
+    // ascending in the key = contig ascending, bucket time descending, own time descending: the list order
+    keys[i] = ((uint64_t)a << (2 * w)) | ((~(uint64_t)minT[b] & mask) << w) | (~(uint64_t)t & mask);
+    vals[i] = g;
+}
+__global__ __launch_bounds__(SO_THREADS) void st_rank_kernel(const uint32_t *__restrict__ vals, uint32_t n, uint32_t *__restrict__ prevrank)
+{
+    const uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x;
+    if (i < n) prevrank[vals[i]] = i;
+}
+// the survivors of the ordered S_1 with their rank as the position
+__global__ __launch_bounds__(SO_THREADS) void st_emit_kernel(SplitTailTab tab, const uint32_t *__restrict__ vals, uint32_t n, const uint8_t *__restrict__ is_surv,
+                                                             const uint32_t *__restrict__ node_rec, csv_split_survivor *__restrict__ out, uint64_t cap,
+                                                             unsigned long long *__restrict__ count)
+{
+    const uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = vals[i];
+    if (!is_surv[g]) return;
+    const unsigned long long slot = atomicAdd(count, 1ull);
+    if (slot < cap) out[slot] = csv_split_survivor{tail_owner(tab, g), i, node_rec[g]};
+}
+
 void launch_so_count(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, uint32_t *blk_cnt)
 {
     if (n_blocks) hipLaunchKernelGGL(so_count_kernel, dim3(n_blocks), dim3(SO_THREADS), 0, s, tab, min_mapq, blk_cnt);
@@ -183,4 +335,50 @@ void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nod
     if (n_nodes) hipLaunchKernelGGL(so_survivors_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, tab, n_nodes, node_hash, node_rec, list, supp_hash, n_supp, out, cap, count);
 }
 
+// ---- launchers of the survivors-only tail
+static inline SplitTailTab to_tab(const SplitTailHost &h)
+{
+    SplitTailTab t;
+    t.A = h.A; t.D = h.D; t.wv = h.wv; t.wa = h.wa;
+    for (uint32_t c = 0; c <= h.A; c++) t.nbase[c] = h.nbase[c];
+    for (uint32_t j = 0; j < SO_TAIL_MAX; j++) {
+        for (uint32_t c = 0; c < SO_MAX_CONTIGS; c++) { t.B[j][c] = c < h.A ? h.B[j][c] : 1u; t.F[j][c] = c < h.A ? h.F[j][c] : 0u; }
+        for (uint32_t c = 0; c <= SO_MAX_CONTIGS; c++) t.boff[j][c] = h.boff[j][c <= h.A ? c : h.A];
+    }
+    return t;
+}
+void launch_st_survivors(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, const uint64_t *node_hash, const uint64_t *supp_hash, uint64_t n_supp, uint8_t *is_surv,
+                         uint32_t *bitmap)
+{
+    if (n_nodes) hipLaunchKernelGGL(st_survivors_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, to_tab(h), n_nodes, node_hash, supp_hash, n_supp, is_surv, bitmap);
+}
+void launch_st_member(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, int j, const uint64_t *node_hash, const uint32_t *bitmap_prev, uint32_t *bitmap_next,
+                      uint32_t *set, unsigned int *count)
+{
+    if (n_nodes) hipLaunchKernelGGL(st_member_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, to_tab(h), n_nodes, j, node_hash, bitmap_prev, bitmap_next, set, count);
+}
+void launch_st_inverse(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, int j_last, const uint32_t *list, uint32_t *prevrank)
+{
+    if (n_nodes) hipLaunchKernelGGL(st_inverse_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, to_tab(h), n_nodes, j_last, list, prevrank);
+}
+void launch_st_mint(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint64_t *node_hash, const uint32_t *prevrank, uint32_t *minT)
+{
+    if (n) hipLaunchKernelGGL(st_mint_kernel, dim3(so_grid(n)), dim3(SO_THREADS), 0, s, to_tab(h), j, set, n, node_hash, prevrank, minT);
+}
+void launch_st_keys(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint64_t *node_hash, const uint32_t *prevrank, const uint32_t *minT,
+                    uint64_t *keys, uint32_t *vals)
+{
+    if (n) hipLaunchKernelGGL(st_keys_kernel, dim3(so_grid(n)), dim3(SO_THREADS), 0, s, to_tab(h), j, set, n, node_hash, prevrank, minT, keys, vals);
+}
+void launch_st_rank(hipStream_t s, const uint32_t *vals, uint32_t n, uint32_t *prevrank)
+{
+    if (n) hipLaunchKernelGGL(st_rank_kernel, dim3(so_grid(n)), dim3(SO_THREADS), 0, s, vals, n, prevrank);
+}
+void launch_st_emit(hipStream_t s, const SplitTailHost &h, const uint32_t *vals, uint32_t n, const uint8_t *is_surv, const uint32_t *node_rec, csv_split_survivor *out,
+                    uint64_t cap, unsigned long long *count)
+{
+    if (n) hipLaunchKernelGGL(st_emit_kernel, dim3(so_grid(n)), dim3(SO_THREADS), 0, s, to_tab(h), vals, n, is_surv, node_rec, out, cap, count);
+}
+
 }  // namespace csv
+

@@ -21,10 +21,27 @@ def _contig(rng, tid, n):
     return reads, names
 
 
+@pytest.fixture(params=[None, 0, 1, 2, 3], ids=["auto", "chain", "tail1", "tail2", "tail3"])
+def tail(request):
+    """CSV_SPLIT_TAIL: how many of every contig's last epochs are ordered for the survivors only (splitorder.hip); None = the library's own
+    choice from the number of nodes per supplementary record, 0 = the full chain of sorts."""
+    import os
+    old = os.environ.pop("CSV_SPLIT_TAIL", None)
+    if request.param is not None:
+        os.environ["CSV_SPLIT_TAIL"] = str(request.param)
+    yield request.param
+    os.environ.pop("CSV_SPLIT_TAIL", None)
+    if old is not None:
+        os.environ["CSV_SPLIT_TAIL"] = old
+
+
+@pytest.mark.parametrize("supp_frac", [0.1, 0.01, 0.6])
 @pytest.mark.parametrize("sizes", [[0, 1, 2, 12, 13, 14, 28, 29, 30, 58, 59, 60, 126, 127, 128, 257, 541, 542, 1109, 2357, 2358, 5087, 5088],
                                    [10273, 10274, 20753, 42043, 42044, 85229, 85230, 3],
                                    [172933, 172934, 351061, 351062, 400_000]])
-def test_split_order_against_a_real_unordered_map(ctx, sizes):
+def test_split_order_against_a_real_unordered_map(ctx, sizes, supp_frac, tail):
+    if supp_frac != 0.1 and len(sizes) != 8:
+        pytest.skip("one size set per extra supplementary fraction")
     rng = np.random.default_rng(len(sizes))
     contigs = [_contig(rng, t, n) for t, n in enumerate(sizes)]
     shards = []
@@ -38,8 +55,8 @@ def test_split_order_against_a_real_unordered_map(ctx, sizes):
             shards.append(sh)
             ok = ((reads.flag & (0x100 | 0x4 | 0x400 | 0x200)) == 0) & (reads.mapq >= 20)
             prim = np.flatnonzero(ok & ((reads.flag & 0x800) == 0))
-            # supplementary names: a tenth of the primaries' names (+ a few names that belong to no primary)
-            has_supp = rng.random(len(prim)) < 0.1
+            # supplementary names: a fraction of the primaries' names (+ a few names that belong to no primary)
+            has_supp = rng.random(len(prim)) < supp_frac
             per.append((names, prim, has_supp))
             supp_names += [names[i] for i in prim[has_supp]] + ["ghost%d_%d" % (t, k) for k in range(3)]
         supp_hash = np.unique(host.string_hashes(supp_names))
