@@ -250,6 +250,16 @@ void launch_so_keys(hipStream_t s, const SplitOrderTab &tab, uint64_t M, uint32_
 void launch_so_setlist(hipStream_t s, const SplitOrderTab &tab, uint64_t M, const uint32_t *vals, uint32_t *list);
 void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nodes, const uint64_t *node_hash, const uint32_t *node_rec, const uint32_t *list,
                          const uint64_t *supp_hash, uint64_t n_supp, csv_split_survivor *out, uint64_t cap, unsigned long long *count);
+// the first epochs (while nodes and buckets fit the LDS) in one launch, one workgroup per contig
+constexpr uint32_t SO_SMALL_B = 5087, SO_SMALL_EPOCHS = 12;
+struct SplitSmallHost {
+    uint32_t A = 0, n_epochs = 0;
+    uint32_t nbase[SO_MAX_CONTIGS + 1] = {0};
+    int32_t  k_last[SO_MAX_CONTIGS] = {0};
+    uint32_t first[SO_SMALL_EPOCHS + 1] = {0};
+    uint32_t B[SO_SMALL_EPOCHS] = {0};
+};
+void launch_so_small_epochs(hipStream_t s, const SplitSmallHost &h, const uint64_t *node_hash, uint32_t *list);
 // the last epochs for the survivors only (splitorder.hip): level j = the contig's last epoch minus j
 constexpr uint32_t SO_TAIL_MAX = 3;
 struct SplitTailHost {

@@ -1188,7 +1188,27 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         for (int j = 1; j <= D; j++) set_n[j] = ((const uint32_t *)ctx->pinned)[j];
     }
 
-    for (size_t k = 0; k < first_node.size(); k++) {
+    // the first epochs (nodes and buckets in LDS) in one launch, one workgroup per contig
+    size_t n_small = 0;
+    {
+        SplitSmallHost sm;
+        while (n_small < first_node.size() && n_small < SO_SMALL_EPOCHS && buckets[n_small] <= SO_SMALL_B) n_small++;
+        const char *e = getenv("CSV_SPLIT_SMALL");
+        if (e && *e && atoi(e) == 0) n_small = 0;                               // (A/B and tests: every epoch through the chain's sorts)
+        sm.A = (uint32_t)n_contigs; sm.n_epochs = (uint32_t)n_small;
+        bool any = false;
+        for (int c = 0; c <= n_contigs; c++) sm.nbase[c] = th.nbase[c];
+        for (int c = 0; c < n_contigs; c++) {
+            int kl = -1;
+            for (size_t k = 0; k < n_small && in_chain(c, k); k++) kl = (int)k;
+            sm.k_last[c] = kl; any |= kl >= 0;
+        }
+        for (size_t k = 0; k <= n_small && k < first_node.size(); k++) sm.first[k] = (uint32_t)std::min<uint64_t>(first_node[k], 0xffffffffu);
+        if (n_small >= first_node.size()) sm.first[n_small] = 0xffffffffu;
+        for (size_t k = 0; k < n_small; k++) sm.B[k] = (uint32_t)buckets[k];
+        if (n_small && any) launch_so_small_epochs(s, sm, node_hash, list);
+    }
+    for (size_t k = n_small; k < first_node.size(); k++) {
         SplitOrderTab e;
         e.A = 0;
         uint64_t M = 0, m_max = 0;
@@ -1219,6 +1239,10 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
     } else {
         // ---- bottom-up: order S_D with the chain's positions, then each smaller set with the ranks of the order before ----
         launch_st_inverse(s, th, (uint32_t)n_nodes, D - 1, list, prevrank);
+        // a t value is a list position or an insertion index (below the largest contig's node count) or a rank in a level's order (below the set's size)
+        uint64_t t_max = n_max;
+        for (int j = 1; j <= D; j++) t_max = std::max<uint64_t>(t_max, set_n[j]);
+        th.wv = std::max(1, bits_of(t_max));
         const int key_bits = th.wa + 2 * (th.wv + 1);
         for (int j = D - 1; j >= 0; j--) {
             const uint32_t n = set_n[j + 1];

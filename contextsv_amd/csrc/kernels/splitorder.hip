@@ -35,6 +35,22 @@ __device__ __forceinline__ bool so_pass(uint16_t flag, uint8_t mapq, uint32_t mi
     return !(flag & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && mapq >= min_mapq;
 }
 
+// h % B for a 32-bit B, exactly, without the 64-bit integer division (some 150 instructions with branches, and every node of every epoch
+// and level pays it): the quotient in two 32-bit steps estimated in double precision (error far below 1), remainder in integers, fixed up.
+__device__ __forceinline__ uint32_t so_mod(uint64_t h, uint32_t B, double inv /* 1.0 / B */)
+{
+    const uint32_t hi = (uint32_t)(h >> 32), lo = (uint32_t)h;
+    int64_t r = (int64_t)hi - (int64_t)((uint64_t)(uint32_t)((double)hi * inv) * B);
+    while (r < 0) r += B;
+    while (r >= (int64_t)B) r -= B;
+    const uint64_t x = ((uint64_t)(uint32_t)r << 32) | lo;                          // < B * 2^32: the quotient fits 32 bits
+    const double xf = fma((double)(uint32_t)r, 4294967296.0, (double)lo);
+    int64_t r2 = (int64_t)(x - (uint64_t)(uint32_t)(xf * inv) * B);
+    while (r2 < 0) r2 += B;
+    while (r2 >= (int64_t)B) r2 -= B;
+    return (uint32_t)r2;
+}
+
 // ---- nodes = the filter-passing primary records in file order (the insertion order of the map) ------------------------------------
 __global__ __launch_bounds__(SO_THREADS) void so_count_kernel(SplitOrderTab tab, uint32_t min_mapq, uint32_t *__restrict__ blk_cnt)
 {
@@ -100,7 +116,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_mint_kernel(SplitOrderTab tab, 
     const uint32_t m = (uint32_t)(tab.work_off[a + 1] - tab.work_off[a]);
     const uint32_t t = m - 1u - (uint32_t)(j - tab.work_off[a]);
     const uint32_t g = so_node_at(tab, a, t, list);
-    const uint32_t b = (uint32_t)(node_hash[g] % (uint64_t)B);
+    const uint32_t b = so_mod(node_hash[g], B, 1.0 / (double)B);
     atomicMin(&minT[(uint64_t)a * B + b], t);
 }
 
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_keys_kernel(SplitOrderTab tab, 
     const uint32_t m = (uint32_t)(tab.work_off[a + 1] - tab.work_off[a]);
     const uint32_t t = m - 1u - (uint32_t)(j - tab.work_off[a]);
     const uint32_t g = so_node_at(tab, a, t, list);
-    const uint32_t b = (uint32_t)(node_hash[g] % (uint64_t)B);
+    const uint32_t b = so_mod(node_hash[g], B, 1.0 / (double)B);
     // One number orders contig and bucket time together: rev_off[a] = items of the contigs behind a, so contig 0 owns the largest
     // values and, sorted descending (ascending in M - 1 - x), comes first, its buckets with the LARGER time first. bits(M - 1) <= 23
     // for a genome: three 8-bit passes.
@@ -154,6 +170,96 @@ __global__ __launch_bounds__(SO_THREADS) void so_survivors_kernel(SplitOrderTab 
     if (slot < cap) out[slot] = csv_split_survivor{a, p, node_rec[g]};
 }
 
+// ---- the first epochs, one launch ---------------------------------------------------------------------------------------------------------
+// The epochs double in size from 13 buckets on, and each costs the chain sixteen launches whatever its size. While an epoch's nodes and
+// buckets fit the LDS (B <= SO_SMALL_B: epochs 0..8, up to 5 087 nodes) ONE workgroup per contig runs through all of them: bucket times by
+// LDS atomicMin, a histogram of the nodes' bucket times and its suffix sums (a bucket's first slot = the nodes in buckets with a later time),
+// slots claimed by LDS atomics and every bucket's few nodes put in descending own time by the bucket's leader — the same order as a stable
+// sort by (bucket time descending) of the nodes enumerated in descending time, which is what the chain's epochs compute.
+struct SplitSmallTab {                       // by value
+    uint32_t A = 0, n_epochs = 0;
+    uint32_t nbase[SO_MAX_CONTIGS + 1];
+    int32_t  k_last[SO_MAX_CONTIGS];         // last epoch this contig runs here (-1: none)
+    uint32_t first[SO_SMALL_EPOCHS + 1];     // first node of epoch k (k = n_epochs: first node of the epoch behind the last one here)
+    uint32_t B[SO_SMALL_EPOCHS];
+};
+__global__ __launch_bounds__(1024) void so_small_epochs_kernel(SplitSmallTab tab, const uint64_t *__restrict__ node_hash, uint32_t *__restrict__ list)
+{
+    constexpr int T = 1024, PER = (SO_SMALL_B + T - 1) / T;
+    __shared__ uint16_t P[SO_SMALL_B];                  // node -> position in the list (its own index until its first epoch)
+    __shared__ uint32_t A1[SO_SMALL_B], A2[SO_SMALL_B], A3[SO_SMALL_B], A4[SO_SMALL_B];
+    __shared__ uint32_t wsum[T / WAVE];
+    const uint32_t a = blockIdx.x;
+    const int k_last = tab.k_last[a];
+    if (k_last < 0) return;
+    const uint32_t N = tab.nbase[a + 1] - tab.nbase[a];
+    const uint64_t *__restrict__ const hash = node_hash + tab.nbase[a];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    uint32_t m = 0;
+    for (int k = 0; k <= k_last; k++) {
+        const uint32_t m_old = tab.first[k], B = tab.B[k];
+        m = min(N, tab.first[k + 1]);
+        const double inv = 1.0 / (double)B;
+        for (uint32_t x = m_old + tid; x < m; x += T) P[x] = (uint16_t)x;
+        for (uint32_t b = tid; b < B; b += T) A1[b] = 0xffffffffu;
+        for (uint32_t t = tid; t < m; t += T) A2[t] = 0;
+        __syncthreads();
+        uint32_t bq[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const uint32_t x = (uint32_t)tid + (uint32_t)i * T;
+            if (x < m) { bq[i] = so_mod(hash[x], B, inv); atomicMin(&A1[bq[i]], (uint32_t)P[x]); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const uint32_t x = (uint32_t)tid + (uint32_t)i * T;
+            if (x < m) { const uint32_t w = A1[bq[i]]; atomicAdd(&A2[w], 1u); A3[x] = (w << 16) | (uint32_t)P[x]; }
+        }
+        __syncthreads();
+        {   // A2[w] <- number of nodes with a bucket time above w (blocked layout over the reversed index), A1 <- 0 (the slot counters)
+            uint32_t v[PER], tot = 0;
+#pragma unroll
+            for (int i = 0; i < PER; i++) { const uint32_t r = (uint32_t)tid * PER + i; v[i] = r < m ? A2[m - 1 - r] : 0u; tot += v[i]; }
+            const uint32_t incl = wave_incl_sum_dpp(tot);
+            if (lane == 63) wsum[wave] = incl;
+            for (uint32_t b = tid; b < m; b += T) A1[b] = 0;
+            __syncthreads();
+            uint32_t run = incl - tot;
+            for (int w2 = 0; w2 < wave; w2++) run += wsum[w2];
+#pragma unroll
+            for (int i = 0; i < PER; i++) { const uint32_t r = (uint32_t)tid * PER + i; if (r < m) A2[m - 1 - r] = run; run += v[i]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const uint32_t x = (uint32_t)tid + (uint32_t)i * T;
+            if (x < m) { const uint32_t wt = A3[x], w = wt >> 16; A4[A2[w] + atomicAdd(&A1[w], 1u)] = (wt << 16) | x; }      // (t << 16) | node
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const uint32_t x = (uint32_t)tid + (uint32_t)i * T;
+            if (x < m) {
+                const uint32_t wt = A3[x];
+                if ((wt >> 16) == (wt & 0xffffu)) {                     // the bucket's leader orders the bucket: descending own time
+                    const uint32_t s0 = A2[wt >> 16], n = A1[wt >> 16];
+                    for (uint32_t i1 = 1; i1 < n; i1++) {
+                        const uint32_t key = A4[s0 + i1];
+                        uint32_t j = i1;
+                        while (j > 0 && A4[s0 + j - 1] < key) { A4[s0 + j] = A4[s0 + j - 1]; j--; }
+                        A4[s0 + j] = key;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = tid; p < m; p += T) P[A4[p] & 0xffffu] = (uint16_t)p;
+        __syncthreads();
+    }
+    for (uint32_t p = tid; p < m; p += T) list[tab.nbase[a] + p] = m > 1 ? (A4[p] & 0xffffu) : 0u;
+}
+
 // ---- the last epochs, survivors only ---------------------------------------------------------------------------------------------------
 // Half of the chain's work is its last epoch, three quarters its last two — and all the caller wants is the relative order of the ~1 % of
 // nodes that survive the erase. The order at the end of an epoch is by (min t of the node's bucket, t), so the order among a SET of nodes
@@ -175,6 +281,7 @@ struct SplitTailTab {                        // passed by value
     uint32_t B[SO_TAIL_MAX][SO_MAX_CONTIGS];           // bucket count of epoch K_c - j (1 where the contig has no such epoch)
     uint32_t F[SO_TAIL_MAX][SO_MAX_CONTIGS];           // first node inserted in that epoch = nodes in the list when it began (0 where no such epoch)
     uint32_t boff[SO_TAIL_MAX][SO_MAX_CONTIGS + 1];    // first bucket of contig c in level j's bucket tables (bitmap bits; minT entries)
+    double   invB[SO_TAIL_MAX][SO_MAX_CONTIGS];        // 1.0 / B
 };
 
 __device__ __forceinline__ uint32_t tail_owner(const SplitTailTab &t, uint32_t g)
@@ -209,7 +316,7 @@ __global__ __launch_bounds__(SO_THREADS) void st_survivors_kernel(SplitTailTab t
     is_surv[g] = sv ? 1 : 0;
     if (sv) {
         const uint32_t a = tail_owner(tab, g);
-        const uint32_t b = tab.boff[0][a] + (uint32_t)(h % (uint64_t)tab.B[0][a]);
+        const uint32_t b = tab.boff[0][a] + so_mod(h, tab.B[0][a], tab.invB[0][a]);
         atomicOr(&bitmap[b >> 5], 1u << (b & 31u));
     }
 }
@@ -230,7 +337,7 @@ __global__ __launch_bounds__(SO_THREADS) void st_member_kernel(SplitTailTab tab,
         const uint32_t lim = j == 1 ? tab.nbase[a + 1] - tab.nbase[a] : tab.F[j - 2][a];        // nodes present at the end of epoch K - (j - 1)
         if (x < lim) {
             h = node_hash[g];
-            const uint32_t b = tab.boff[j - 1][a] + (uint32_t)(h % (uint64_t)tab.B[j - 1][a]);
+            const uint32_t b = tab.boff[j - 1][a] + so_mod(h, tab.B[j - 1][a], tab.invB[j - 1][a]);
             in = (bitmap_prev[b >> 5] >> (b & 31u)) & 1u;
         }
     }
@@ -238,7 +345,7 @@ __global__ __launch_bounds__(SO_THREADS) void st_member_kernel(SplitTailTab tab,
     if (in) {
         set[slot] = g;
         if (bitmap_next && x < tab.F[j - 1][a]) {
-            const uint32_t b = tab.boff[j][a] + (uint32_t)(h % (uint64_t)tab.B[j][a]);
+            const uint32_t b = tab.boff[j][a] + so_mod(h, tab.B[j][a], tab.invB[j][a]);
             atomicOr(&bitmap_next[b >> 5], 1u << (b & 31u));
         }
     }
@@ -269,7 +376,7 @@ __global__ __launch_bounds__(SO_THREADS) void st_mint_kernel(SplitTailTab tab, i
     if (i >= n) return;
     const uint32_t g = set[i];
     const uint32_t a = tail_owner(tab, g);
-    const uint32_t b = tab.boff[j][a] + (uint32_t)(node_hash[g] % (uint64_t)tab.B[j][a]);
+    const uint32_t b = tab.boff[j][a] + so_mod(node_hash[g], tab.B[j][a], tab.invB[j][a]);
     atomicMin(&minT[b], st_t(tab, j, a, g - tab.nbase[a], g, prevrank));
 }
 __global__ __launch_bounds__(SO_THREADS) void st_keys_kernel(SplitTailTab tab, int j, const uint32_t *__restrict__ set, uint32_t n, const uint64_t *__restrict__ node_hash,
@@ -280,7 +387,7 @@ __global__ __launch_bounds__(SO_THREADS) void st_keys_kernel(SplitTailTab tab, i
     if (i >= n) return;
     const uint32_t g = set[i];
     const uint32_t a = tail_owner(tab, g);
-    const uint32_t b = tab.boff[j][a] + (uint32_t)(node_hash[g] % (uint64_t)tab.B[j][a]);
+    const uint32_t b = tab.boff[j][a] + so_mod(node_hash[g], tab.B[j][a], tab.invB[j][a]);
     const uint32_t t = st_t(tab, j, a, g - tab.nbase[a], g, prevrank);
     const int w = tab.wv + 1;
     const uint64_t mask = (1ull << w) - 1ull;
@@ -335,6 +442,18 @@ void launch_so_survivors(hipStream_t s, const SplitOrderTab &tab, uint64_t n_nod
     if (n_nodes) hipLaunchKernelGGL(so_survivors_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, tab, n_nodes, node_hash, node_rec, list, supp_hash, n_supp, out, cap, count);
 }
 
+void launch_so_small_epochs(hipStream_t s, const SplitSmallHost &h, const uint64_t *node_hash, uint32_t *list)
+{
+    if (!h.A || !h.n_epochs) return;
+    SplitSmallTab t;
+    t.A = h.A; t.n_epochs = h.n_epochs;
+    for (uint32_t c = 0; c <= SO_MAX_CONTIGS; c++) t.nbase[c] = h.nbase[c <= h.A ? c : h.A];
+    for (uint32_t c = 0; c < SO_MAX_CONTIGS; c++) t.k_last[c] = c < h.A ? h.k_last[c] : -1;
+    for (uint32_t k = 0; k <= SO_SMALL_EPOCHS; k++) t.first[k] = h.first[k];
+    for (uint32_t k = 0; k < SO_SMALL_EPOCHS; k++) t.B[k] = h.B[k];
+    hipLaunchKernelGGL(so_small_epochs_kernel, dim3(h.A), dim3(1024), 0, s, t, node_hash, list);
+}
+
 // ---- launchers of the survivors-only tail
 static inline SplitTailTab to_tab(const SplitTailHost &h)
 {
@@ -342,7 +461,7 @@ static inline SplitTailTab to_tab(const SplitTailHost &h)
     t.A = h.A; t.D = h.D; t.wv = h.wv; t.wa = h.wa;
     for (uint32_t c = 0; c <= h.A; c++) t.nbase[c] = h.nbase[c];
     for (uint32_t j = 0; j < SO_TAIL_MAX; j++) {
-        for (uint32_t c = 0; c < SO_MAX_CONTIGS; c++) { t.B[j][c] = c < h.A ? h.B[j][c] : 1u; t.F[j][c] = c < h.A ? h.F[j][c] : 0u; }
+        for (uint32_t c = 0; c < SO_MAX_CONTIGS; c++) { t.B[j][c] = c < h.A ? h.B[j][c] : 1u; t.F[j][c] = c < h.A ? h.F[j][c] : 0u; t.invB[j][c] = 1.0 / (double)t.B[j][c]; }
         for (uint32_t c = 0; c <= SO_MAX_CONTIGS; c++) t.boff[j][c] = h.boff[j][c <= h.A ? c : h.A];
     }
     return t;

@@ -21,18 +21,22 @@ def _contig(rng, tid, n):
     return reads, names
 
 
-@pytest.fixture(params=[None, 0, 1, 2, 3], ids=["auto", "chain", "tail1", "tail2", "tail3"])
+@pytest.fixture(params=[(None, None), (0, None), (1, None), (2, None), (3, None), (0, 0), (2, 0)],
+                ids=["auto", "chain", "tail1", "tail2", "tail3", "chain-nosmall", "tail2-nosmall"])
 def tail(request):
     """CSV_SPLIT_TAIL: how many of every contig's last epochs are ordered for the survivors only (splitorder.hip); None = the library's own
-    choice from the number of nodes per supplementary record, 0 = the full chain of sorts."""
+    choice from the number of nodes per supplementary record, 0 = the full chain of sorts. CSV_SPLIT_SMALL=0: the first epochs through the
+    chain's sorts as well instead of the one-launch LDS kernel."""
     import os
-    old = os.environ.pop("CSV_SPLIT_TAIL", None)
-    if request.param is not None:
-        os.environ["CSV_SPLIT_TAIL"] = str(request.param)
+    old = {k: os.environ.pop(k, None) for k in ("CSV_SPLIT_TAIL", "CSV_SPLIT_SMALL")}
+    for k, v in zip(("CSV_SPLIT_TAIL", "CSV_SPLIT_SMALL"), request.param):
+        if v is not None:
+            os.environ[k] = str(v)
     yield request.param
-    os.environ.pop("CSV_SPLIT_TAIL", None)
-    if old is not None:
-        os.environ["CSV_SPLIT_TAIL"] = old
+    for k, v in old.items():
+        os.environ.pop(k, None)
+        if v is not None:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("supp_frac", [0.1, 0.01, 0.6])
