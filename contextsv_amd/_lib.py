@@ -87,6 +87,8 @@ ABI = {
     "csvgpu_aln_intervals_gather_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "csvgpu_shard_set_qname_hash": (C.c_int, [_P, _P, _P]),
     "csvgpu_split_order": (C.c_int, [_P, C.c_int, _P, C.c_uint8, _P, C.c_uint64, _P, C.c_uint64, _P]),
+    "csvgpu_split_order_begin": (C.c_int, [_P, C.c_int, _P, C.c_uint8]),
+    "csvgpu_split_order_finish": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _P]),
     "csvgpu_window_log2_resident": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_double, _P, _P, _P]),
     "csvgpu_window_log2_resident_many": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "csvgpu_chr_fetch": (C.c_int, [_P, _P, C.POINTER(csv_chr_result), _P, _P]),

@@ -193,6 +193,23 @@ class Context:
         self._check(rc)
         return [out[int(off[k]): int(off[k + 1])].copy() for k in range(n)]
 
+    def split_order_two_calls(self, shards, min_mapq: int, supp_hash, capacity: int = 4):
+        """csvgpu_split_order_begin (everything that needs no supplementary record, queued) + csvgpu_split_order_finish; a too small
+        `capacity` exercises the retry of _finish after CSV_ECAPACITY."""
+        supp_hash = np.ascontiguousarray(supp_hash, np.uint64)
+        n = len(shards)
+        hs = (C.c_void_p * max(n, 1))(*[s.h for s in shards])
+        self._check(self.lib.csvgpu_split_order_begin(self.h, n, hs, min_mapq))
+        out = np.zeros(max(capacity, 1), np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        rc = self.lib.csvgpu_split_order_finish(self.h, ptr(supp_hash), len(supp_hash), ptr(out), capacity, ptr(off))
+        if rc == _lib.CSV_ECAPACITY:
+            capacity = int(off[n])
+            out = np.zeros(max(capacity, 1), np.uint32)
+            rc = self.lib.csvgpu_split_order_finish(self.h, ptr(supp_hash), len(supp_hash), ptr(out), capacity, ptr(off))
+        self._check(rc)
+        return [out[int(off[k]): int(off[k + 1])].copy() for k in range(n)]
+
     # -------------------------------------------------------------------------------- timing
     def synchronize(self):
         self._check(self.lib.csvgpu_synchronize(self.h))

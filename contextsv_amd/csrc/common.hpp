@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -71,6 +72,7 @@ struct csv_ctx {
     char        *job_pin = nullptr;         // page-locked counter slots of the jobs in flight (csvgpu_chr_job_*)
     size_t       job_pin_next = 0;
     uint32_t     job_pin_busy = 0;          // bit i: slot i belongs to a job between begin and end / abort
+    struct csv_split_state *split_state = nullptr;   // between csvgpu_split_order_begin and _finish
 };
 
 struct csv_shard {
@@ -270,8 +272,9 @@ struct SplitTailHost {
     uint32_t F[SO_TAIL_MAX][SO_MAX_CONTIGS] = {{0}};
     uint32_t boff[SO_TAIL_MAX][SO_MAX_CONTIGS + 1] = {{0}};
 };
-void launch_st_survivors(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, const uint64_t *node_hash, const uint64_t *supp_hash, uint64_t n_supp, uint8_t *is_surv,
-                         uint32_t *bitmap);
+size_t st_filter_bytes();
+void launch_st_survivors(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, const uint64_t *node_hash, const uint64_t *supp_hash, uint64_t n_supp, uint32_t *filter /* st_filter_bytes(), zeroed */,
+                         uint8_t *is_surv, uint32_t *bitmap);
 void launch_st_member(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, int j, const uint64_t *node_hash, const uint32_t *bitmap_prev, uint32_t *bitmap_next,
                       uint32_t *set, unsigned int *count);
 void launch_st_inverse(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, int j_last, const uint32_t *list, uint32_t *prevrank);

@@ -402,6 +402,7 @@ static csv_ctx *create_ctx(int device_ordinal, void *stream, int low_priority)
     return ctx;
 }
 
+static void split_state_free(csv_ctx *ctx);
 void csvgpu_destroy(csv_ctx *ctx)
 {
     if (!ctx) return;
@@ -417,6 +418,7 @@ void csvgpu_destroy(csv_ctx *ctx)
     for (auto &b : ctx->host_live) (void)hipHostFree(b.first);       // blocks the caller never returned
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    split_state_free(ctx);
     delete ctx;
 }
 
@@ -1054,18 +1056,45 @@ static void split_order_epochs(uint64_t n_max, std::vector<uint64_t> &first_node
     first_node = c_first; buckets = c_bkt;
 }
 
-int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq, const uint64_t *supp_hash, uint64_t n_supp,
-                       uint32_t *out_rec, uint64_t capacity, uint64_t *out_off)
+}  // extern "C"
+
+// What csvgpu_split_order_begin leaves for csvgpu_split_order_finish (one pending order per context; device pointers into ctx->arena / ctx->work).
+struct csv_split_state {
+    int n_contigs = 0;
+    SplitOrderTab tab;
+    std::vector<uint64_t> N;
+    uint64_t n_nodes = 0, n_max = 0, total_reads = 0;
+    int D = 0;
+    SplitTailHost th;
+    uint64_t *node_hash = nullptr, *d_supp = nullptr;
+    uint32_t *node_rec = nullptr, *list = nullptr, *minT = nullptr;
+    SortWs w;
+    csv_split_survivor *d_out = nullptr;
+    unsigned long long *d_count = nullptr;
+    uint32_t *bitmap[SO_TAIL_MAX] = {nullptr, nullptr, nullptr}, *set[SO_TAIL_MAX + 1] = {nullptr, nullptr, nullptr, nullptr}, *prevrank = nullptr, *filter = nullptr;
+    uint8_t *is_surv = nullptr;
+    size_t bm_words = 0;
+    bool finished = false;
+    std::vector<csv_split_survivor> surv;
+    std::vector<uint64_t> off;
+};
+
+static void split_state_free(csv_ctx *ctx) { if (ctx) { delete ctx->split_state; ctx->split_state = nullptr; } }
+
+// nodes + every epoch that does not depend on the supplementary records: queued, not waited for (beyond the node counts)
+static int split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq, int64_t n_supp_hint /* < 0: unknown */)
 {
     if (!ctx) return CSV_EINVAL;
+    delete ctx->split_state; ctx->split_state = nullptr;
     if (n_contigs < 0 || (uint32_t)n_contigs > SO_MAX_CONTIGS) { ctx->err = "split_order: at most 32 contigs per call"; return CSV_EINVAL; }
-    if (!out_off || (n_contigs && !shards) || (n_supp && !supp_hash) || (capacity && !out_rec)) { ctx->err = "split_order: null array"; return CSV_EINVAL; }
-    for (int c = 0; c <= n_contigs; c++) out_off[c] = 0;
-    if (n_contigs == 0) return CSV_OK;
-    for (uint64_t i = 1; i < n_supp; i++) if (supp_hash[i] <= supp_hash[i - 1]) { ctx->err = "split_order: supp_hash must be sorted and distinct"; return CSV_EINVAL; }
+    if (n_contigs && !shards) { ctx->err = "split_order: null array"; return CSV_EINVAL; }
+    std::unique_ptr<csv_split_state> st(new csv_split_state());
+    st->n_contigs = n_contigs;
+    st->off.assign((size_t)n_contigs + 1, 0);
+    if (n_contigs == 0) { st->finished = true; ctx->split_state = st.release(); return CSV_OK; }
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    SplitOrderTab tab;
+    SplitOrderTab &tab = st->tab;
     tab.A = (uint32_t)n_contigs;
     uint64_t total_reads = 0, n_blocks = 0;
     for (int c = 0; c < n_contigs; c++) {
@@ -1077,21 +1106,23 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         total_reads += sh->d.n_reads;
     }
     tab.blk_off[n_contigs] = n_blocks;
-    if (total_reads == 0 || n_supp == 0) return CSV_OK;
+    st->total_reads = total_reads;
+    if (total_reads == 0 || n_supp_hint == 0) { st->finished = true; ctx->split_state = st.release(); return CSV_OK; }
     if (total_reads >= 0xfffffff0ull) { ctx->err = "split_order: too many records in one call"; return CSV_EINVAL; }
     TimerScope ts(ctx, CSV_K_SPLIT_ORDER);
 
     // ---- nodes: the filter-passing primaries of every contig, file order ----
+    // (the supplementary hashes arrive with _finish: at most one per record)
     int rc = arena_reserve(ctx, ctx->arena, align_up((n_blocks + 1) * 4, 256) + exclusive_sum_tmp_bytes(n_blocks + 1) + align_up(total_reads * 8, 256) +
-                                                2 * align_up(total_reads * 4, 256) + align_up(n_supp * 8, 256) + 4096);
+                                                2 * align_up(total_reads * 4, 256) + align_up(total_reads * 8, 256) + 4096);
     if (rc) return rc;
     uint32_t *blk = (uint32_t *)arena_alloc(ctx->arena, (n_blocks + 1) * 4);
     void *es_tmp = arena_alloc(ctx->arena, exclusive_sum_tmp_bytes(n_blocks + 1));
     uint64_t *node_hash = (uint64_t *)arena_alloc(ctx->arena, total_reads * 8);
     uint32_t *node_rec = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4), *list = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4);
-    uint64_t *d_supp = (uint64_t *)arena_alloc(ctx->arena, n_supp * 8);
-    if (!blk || !es_tmp || !node_hash || !node_rec || !list || !d_supp) { ctx->err = "arena exhausted (split order)"; return CSV_ENOMEM; }
-    CSV_HIP(ctx, hipMemcpyAsync(d_supp, supp_hash, n_supp * 8, hipMemcpyHostToDevice, s));
+    st->d_supp = (uint64_t *)arena_alloc(ctx->arena, total_reads * 8);
+    if (!blk || !es_tmp || !node_hash || !node_rec || !list || !st->d_supp) { ctx->err = "arena exhausted (split order)"; return CSV_ENOMEM; }
+    st->node_hash = node_hash; st->node_rec = node_rec; st->list = list;
     CSV_HIP(ctx, hipMemsetAsync(blk + n_blocks, 0, 4, s));
     launch_so_count(s, tab, (uint32_t)n_blocks, min_mapq, blk);
     launch_exclusive_sum_u32(s, blk, n_blocks + 1, es_tmp);
@@ -1100,7 +1131,8 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
     CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, blk, (n_blocks + 1) * 4, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, wait_stream(s));
     const uint32_t *h_blk = (const uint32_t *)ctx->pinned;
-    std::vector<uint64_t> N((size_t)n_contigs);
+    std::vector<uint64_t> &N = st->N;
+    N.assign((size_t)n_contigs, 0);
     uint64_t n_nodes = h_blk[n_blocks], n_max = 0;
     for (int c = 0; c < n_contigs; c++) {
         tab.nbase[c] = h_blk[tab.blk_off[c]];
@@ -1108,21 +1140,23 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         n_max = std::max(n_max, N[(size_t)c]);
     }
     tab.nbase[n_contigs] = (uint32_t)n_nodes;
-    if (n_nodes == 0) return CSV_OK;
+    st->n_nodes = n_nodes; st->n_max = n_max;
+    if (n_nodes == 0) { st->finished = true; ctx->split_state = st.release(); return CSV_OK; }
 
     // ---- the chain of epochs: a contig takes part in epoch k while it still has nodes inserted at or after the epoch's first node ----
     std::vector<uint64_t> first_node, buckets;
     split_order_epochs(n_max, first_node, buckets);
     // The last D epochs of every contig are ordered for the survivors (and the nodes their order depends on) only: splitorder.hip.
-    // The sets double per level and the epochs halve, so D levels pay while 4^D <= nodes per supplementary record.
+    // The sets double per level and the epochs halve, so D levels pay while 4^D <= nodes per supplementary record (about a hundred
+    // in a long-read run: D = 3, also taken when the caller has not counted its supplementary records yet).
     int D = 0;
     {
-        const uint64_t ratio = n_nodes / std::max<uint64_t>(n_supp, 1);
+        const uint64_t ratio = n_supp_hint > 0 ? n_nodes / (uint64_t)n_supp_hint : (n_nodes >= 4096 ? 64 : 1);
         while (D < (int)SO_TAIL_MAX && (ratio >> (2 * (D + 1))) >= 1) D++;
         const char *e = getenv("CSV_SPLIT_TAIL");
         if (e && *e) D = std::min<int>(std::max(atoi(e), 0), (int)SO_TAIL_MAX);
     }
-    SplitTailHost th;
+    SplitTailHost &th = st->th;
     th.A = (uint32_t)n_contigs; th.wv = std::max(1, bits_of(n_nodes)); th.wa = std::max(1, bits_of((uint64_t)n_contigs - 1));
     if (n_nodes >= (1ull << 31) || th.wa + 2 * (th.wv + 1) > 64) D = 0;
     th.D = (uint32_t)D;
@@ -1146,6 +1180,7 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         for (int c = n_contigs; c <= (int)SO_MAX_CONTIGS; c++) th.boff[j][c] = (uint32_t)off;
         tail_buckets = std::max(tail_buckets, off);
     }
+    st->D = D;
     auto in_chain = [&](int c, size_t k) { return N[(size_t)c] > first_node[k] && (int)k <= K[(size_t)c] - D; };
     uint64_t scratch = tail_buckets * 4;
     for (size_t k = 0; k < first_node.size(); k++) {
@@ -1153,39 +1188,27 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         for (int c = 0; c < n_contigs; c++) A += in_chain(c, k);
         scratch = std::max(scratch, A * buckets[k] * 4);
     }
-    const size_t bm_words = (size_t)((tail_buckets + 31) / 32 + 8);
+    const size_t bm_words = st->bm_words = (size_t)((tail_buckets + 31) / 32 + 8);
     if ((rc = arena_reserve(ctx, ctx->work, align_up(scratch + 16, 256) + sortws_bytes(n_nodes) + align_up(n_nodes * sizeof(csv_split_survivor), 256) +
-                                                (size_t)D * (align_up(bm_words * 4, 256) + align_up(n_nodes * 4, 256)) + align_up(n_nodes, 256) + align_up(n_nodes * 4, 256) + 8192))) return rc;
-    uint32_t *minT = (uint32_t *)arena_alloc(ctx->work, scratch + 16);
-    SortWs w;
+                                                (size_t)D * (align_up(bm_words * 4, 256) + align_up(n_nodes * 4, 256)) + align_up(n_nodes, 256) + align_up(n_nodes * 4, 256) +
+                                                align_up(st_filter_bytes(), 256) + 8192))) return rc;
+    uint32_t *minT = st->minT = (uint32_t *)arena_alloc(ctx->work, scratch + 16);
+    SortWs &w = st->w;
     if (!minT || !sortws_carve(ctx->work, n_nodes, w)) { ctx->err = "arena exhausted (split order epochs)"; return CSV_ENOMEM; }
-    const uint64_t cap = n_nodes;
-    csv_split_survivor *d_out = (csv_split_survivor *)arena_alloc(ctx->work, cap * sizeof(csv_split_survivor));
-    unsigned long long *d_count = (unsigned long long *)arena_alloc(ctx->work, 256);      // [0] survivors; 32-bit set sizes from byte 64 on
-    if (!d_out || !d_count) { ctx->err = "arena exhausted (split order survivors)"; return CSV_ENOMEM; }
-    CSV_HIP(ctx, hipMemsetAsync(d_count, 0, 256, s));
-    unsigned int *d_setn = (unsigned int *)((char *)d_count + 64);
-
-    // ---- top-down: who takes part in the last D epochs (hashes only; needs nothing of the chain) ----
-    uint32_t *bitmap[SO_TAIL_MAX] = {nullptr, nullptr, nullptr}, *set[SO_TAIL_MAX + 1] = {nullptr, nullptr, nullptr, nullptr}, *prevrank = nullptr;
-    uint8_t *is_surv = nullptr;
-    uint32_t set_n[SO_TAIL_MAX + 1] = {0, 0, 0, 0};
+    st->d_out = (csv_split_survivor *)arena_alloc(ctx->work, n_nodes * sizeof(csv_split_survivor));
+    st->d_count = (unsigned long long *)arena_alloc(ctx->work, 256);      // [0] survivors; 32-bit set sizes from byte 64 on
+    if (!st->d_out || !st->d_count) { ctx->err = "arena exhausted (split order survivors)"; return CSV_ENOMEM; }
+    CSV_HIP(ctx, hipMemsetAsync(st->d_count, 0, 256, s));
     if (D > 0) {
         for (int j = 0; j < D; j++) {
-            bitmap[j] = (uint32_t *)arena_alloc(ctx->work, bm_words * 4);
-            set[j + 1] = (uint32_t *)arena_alloc(ctx->work, n_nodes * 4);
-            if (!bitmap[j] || !set[j + 1]) { ctx->err = "arena exhausted (split order tail)"; return CSV_ENOMEM; }
-            CSV_HIP(ctx, hipMemsetAsync(bitmap[j], 0, bm_words * 4, s));
+            st->bitmap[j] = (uint32_t *)arena_alloc(ctx->work, bm_words * 4);
+            st->set[j + 1] = (uint32_t *)arena_alloc(ctx->work, n_nodes * 4);
+            if (!st->bitmap[j] || !st->set[j + 1]) { ctx->err = "arena exhausted (split order tail)"; return CSV_ENOMEM; }
         }
-        is_surv = (uint8_t *)arena_alloc(ctx->work, n_nodes);
-        prevrank = (uint32_t *)arena_alloc(ctx->work, n_nodes * 4);
-        if (!is_surv || !prevrank) { ctx->err = "arena exhausted (split order tail)"; return CSV_ENOMEM; }
-        launch_st_survivors(s, th, (uint32_t)n_nodes, node_hash, d_supp, n_supp, is_surv, bitmap[0]);
-        for (int j = 1; j <= D; j++)
-            launch_st_member(s, th, (uint32_t)n_nodes, j, node_hash, bitmap[j - 1], j < D ? bitmap[j] : nullptr, set[j], d_setn + j);
-        CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_setn, 16, hipMemcpyDeviceToHost, s));
-        CSV_HIP(ctx, wait_stream(s));
-        for (int j = 1; j <= D; j++) set_n[j] = ((const uint32_t *)ctx->pinned)[j];
+        st->is_surv = (uint8_t *)arena_alloc(ctx->work, n_nodes);
+        st->prevrank = (uint32_t *)arena_alloc(ctx->work, n_nodes * 4);
+        st->filter = (uint32_t *)arena_alloc(ctx->work, st_filter_bytes());
+        if (!st->is_surv || !st->prevrank || !st->filter) { ctx->err = "arena exhausted (split order tail)"; return CSV_ENOMEM; }
     }
 
     // the first epochs (nodes and buckets in LDS) in one launch, one workgroup per contig
@@ -1232,44 +1255,121 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
         const int io = launch_radix_sort_u64(s, w.k0, w.v0, w.k1, w.v1, M, key_bits, w.tmp);
         launch_so_setlist(s, e, M, io ? w.v1 : w.v0, list);
     }
+    if (D > 0) launch_st_inverse(s, th, (uint32_t)n_nodes, D - 1, list, st->prevrank);
+    if (hipGetLastError() != hipSuccess) { ctx->err = "split_order: launch failed"; return CSV_EHIP; }
+    ctx->split_state = st.release();
+    return CSV_OK;
+}
 
-    if (D == 0) {
-        // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
-        launch_so_survivors(s, tab, n_nodes, node_hash, node_rec, list, d_supp, n_supp, d_out, cap, d_count);
-    } else {
-        // ---- bottom-up: order S_D with the chain's positions, then each smaller set with the ranks of the order before ----
-        launch_st_inverse(s, th, (uint32_t)n_nodes, D - 1, list, prevrank);
-        // a t value is a list position or an insertion index (below the largest contig's node count) or a rank in a level's order (below the set's size)
-        uint64_t t_max = n_max;
-        for (int j = 1; j <= D; j++) t_max = std::max<uint64_t>(t_max, set_n[j]);
-        th.wv = std::max(1, bits_of(t_max));
-        const int key_bits = th.wa + 2 * (th.wv + 1);
-        for (int j = D - 1; j >= 0; j--) {
-            const uint32_t n = set_n[j + 1];
-            if (n == 0) continue;
-            CSV_HIP(ctx, hipMemsetAsync(minT, 0xff, (size_t)th.boff[j][n_contigs] * 4, s));
-            launch_st_mint(s, th, j, set[j + 1], n, node_hash, prevrank, minT);
-            launch_st_keys(s, th, j, set[j + 1], n, node_hash, prevrank, minT, w.k0, w.v0);
-            const int io = launch_radix_sort_u64(s, w.k0, w.v0, w.k1, w.v1, n, key_bits, w.tmp);
-            const uint32_t *sorted = n > 1 ? (io ? w.v1 : w.v0) : w.v0;
-            if (j > 0) launch_st_rank(s, sorted, n, prevrank);
-            else launch_st_emit(s, th, sorted, n, is_surv, node_rec, d_out, cap, d_count);
+static int split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t n_supp, uint32_t *out_rec, uint64_t capacity, uint64_t *out_off)
+{
+    if (!ctx) return CSV_EINVAL;
+    csv_split_state *st = ctx->split_state;
+    if (!st) { ctx->err = "split_order_finish without split_order_begin"; return CSV_EINVAL; }
+    const int n_contigs = st->n_contigs;
+    if (!out_off || (n_supp && !supp_hash) || (capacity && !out_rec)) { ctx->err = "split_order: null array"; return CSV_EINVAL; }
+    for (uint64_t i = 1; i < n_supp; i++) if (supp_hash[i] <= supp_hash[i - 1]) { ctx->err = "split_order: supp_hash must be sorted and distinct"; return CSV_EINVAL; }
+    for (int c = 0; c <= n_contigs; c++) out_off[c] = 0;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    if (!st->finished) {
+        if (n_supp == 0) {               // nothing survives
+            CSV_HIP(ctx, wait_stream(s));
+            st->finished = true;
         }
     }
-    CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_count, 8, hipMemcpyDeviceToHost, s));
-    CSV_HIP(ctx, wait_stream(s));
-    const uint64_t n_surv = *(const unsigned long long *)ctx->pinned;
-    std::vector<csv_split_survivor> surv(n_surv);
-    if (n_surv) {
-        CSV_HIP(ctx, hipMemcpyAsync(surv.data(), d_out, n_surv * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
+    if (!st->finished) {
+        TimerScope ts(ctx, CSV_K_SPLIT_ORDER);
+        const int D = st->D;
+        SplitTailHost &th = st->th;
+        SortWs &w = st->w;
+        const uint64_t n_nodes = st->n_nodes, cap = n_nodes;
+        // (room for one hash per record of these contigs was set aside by _begin; a run's other contigs can add more)
+        struct TmpBuf { void *p = nullptr; ~TmpBuf() { if (p) (void)hipFree(p); } } big_supp;
+        uint64_t *d_supp = st->d_supp;
+        if (n_supp > st->total_reads) {
+            if (hipMalloc(&big_supp.p, n_supp * 8) != hipSuccess) { (void)hipGetLastError(); big_supp.p = nullptr; ctx->err = "hipMalloc failed (supplementary hashes)"; return CSV_ENOMEM; }
+            d_supp = (uint64_t *)big_supp.p;
+        }
+        CSV_HIP(ctx, hipMemcpyAsync(d_supp, supp_hash, n_supp * 8, hipMemcpyHostToDevice, s));
+        if (D == 0) {
+            // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
+            launch_so_survivors(s, st->tab, n_nodes, st->node_hash, st->node_rec, st->list, d_supp, n_supp, st->d_out, cap, st->d_count);
+        } else {
+            // ---- top-down: who takes part in the last D epochs (hashes only) ----
+            unsigned int *d_setn = (unsigned int *)((char *)st->d_count + 64);
+            uint32_t set_n[SO_TAIL_MAX + 1] = {0, 0, 0, 0};
+            for (int j = 0; j < D; j++) CSV_HIP(ctx, hipMemsetAsync(st->bitmap[j], 0, st->bm_words * 4, s));
+            CSV_HIP(ctx, hipMemsetAsync(st->filter, 0, st_filter_bytes(), s));
+            launch_st_survivors(s, th, (uint32_t)n_nodes, st->node_hash, d_supp, n_supp, st->filter, st->is_surv, st->bitmap[0]);
+            for (int j = 1; j <= D; j++)
+                launch_st_member(s, th, (uint32_t)n_nodes, j, st->node_hash, st->bitmap[j - 1], j < D ? st->bitmap[j] : nullptr, st->set[j], d_setn + j);
+            CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_setn, 16, hipMemcpyDeviceToHost, s));
+            CSV_HIP(ctx, wait_stream(s));
+            for (int j = 1; j <= D; j++) set_n[j] = ((const uint32_t *)ctx->pinned)[j];
+            // ---- bottom-up: order S_D with the chain's positions, then each smaller set with the ranks of the order before ----
+            // a t value is a list position or an insertion index (below the largest contig's node count) or a rank in a level's order (below the set's size)
+            uint64_t t_max = st->n_max;
+            for (int j = 1; j <= D; j++) t_max = std::max<uint64_t>(t_max, set_n[j]);
+            th.wv = std::max(1, bits_of(t_max));
+            const int key_bits = th.wa + 2 * (th.wv + 1);
+            for (int j = D - 1; j >= 0; j--) {
+                const uint32_t n = set_n[j + 1];
+                if (n == 0) continue;
+                CSV_HIP(ctx, hipMemsetAsync(st->minT, 0xff, (size_t)th.boff[j][n_contigs] * 4, s));
+                launch_st_mint(s, th, j, st->set[j + 1], n, st->node_hash, st->prevrank, st->minT);
+                launch_st_keys(s, th, j, st->set[j + 1], n, st->node_hash, st->prevrank, st->minT, w.k0, w.v0);
+                const int io = launch_radix_sort_u64(s, w.k0, w.v0, w.k1, w.v1, n, key_bits, w.tmp);
+                const uint32_t *sorted = n > 1 ? (io ? w.v1 : w.v0) : w.v0;
+                if (j > 0) launch_st_rank(s, sorted, n, st->prevrank);
+                else launch_st_emit(s, th, sorted, n, st->is_surv, st->node_rec, st->d_out, cap, st->d_count);
+            }
+        }
+        CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, st->d_count, 8, hipMemcpyDeviceToHost, s));
         CSV_HIP(ctx, wait_stream(s));
+        const uint64_t n_surv = *(const unsigned long long *)ctx->pinned;
+        std::vector<csv_split_survivor> &surv = st->surv;
+        surv.resize(n_surv);
+        if (n_surv) {
+            CSV_HIP(ctx, hipMemcpyAsync(surv.data(), st->d_out, n_surv * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
+            CSV_HIP(ctx, wait_stream(s));
+        }
+        std::sort(surv.begin(), surv.end(), [](const csv_split_survivor &a, const csv_split_survivor &b) { return a.contig != b.contig ? a.contig < b.contig : a.pos < b.pos; });
+        for (const csv_split_survivor &v : surv) st->off[v.contig + 1]++;
+        for (int c = 0; c < n_contigs; c++) st->off[(size_t)c + 1] += st->off[(size_t)c];
+        st->finished = true;
     }
-    std::sort(surv.begin(), surv.end(), [](const csv_split_survivor &a, const csv_split_survivor &b) { return a.contig != b.contig ? a.contig < b.contig : a.pos < b.pos; });
-    for (const csv_split_survivor &v : surv) out_off[v.contig + 1]++;
-    for (int c = 0; c < n_contigs; c++) out_off[c + 1] += out_off[c];
-    if (n_surv > capacity) { ctx->err = "split_order: output capacity too small"; return CSV_ECAPACITY; }
-    for (uint64_t i = 0; i < n_surv; i++) out_rec[i] = surv[i].rec;
+    for (int c = 0; c <= n_contigs; c++) out_off[c] = st->off[(size_t)c];
+    if (st->surv.size() > capacity) { ctx->err = "split_order: output capacity too small"; return CSV_ECAPACITY; }      // (the state stays: _finish again with more room)
+    for (size_t i = 0; i < st->surv.size(); i++) out_rec[i] = st->surv[i].rec;
+    delete st; ctx->split_state = nullptr;
     return CSV_OK;
+}
+
+extern "C" {
+
+int csvgpu_split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq)
+{
+    return split_order_begin(ctx, n_contigs, shards, min_mapq, -1);
+}
+
+int csvgpu_split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t n_supp, uint32_t *out_rec, uint64_t capacity, uint64_t *out_off)
+{
+    return split_order_finish(ctx, supp_hash, n_supp, out_rec, capacity, out_off);
+}
+
+int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq, const uint64_t *supp_hash, uint64_t n_supp,
+                       uint32_t *out_rec, uint64_t capacity, uint64_t *out_off)
+{
+    if (!ctx) return CSV_EINVAL;
+    if (!out_off || (n_contigs > 0 && !shards) || (n_supp && !supp_hash) || (capacity && !out_rec)) { ctx->err = "split_order: null array"; return CSV_EINVAL; }
+    if (n_contigs >= 0 && (uint32_t)n_contigs <= SO_MAX_CONTIGS) for (int c = 0; c <= n_contigs; c++) out_off[c] = 0;
+    for (uint64_t i = 1; i < n_supp; i++) if (supp_hash[i] <= supp_hash[i - 1]) { ctx->err = "split_order: supp_hash must be sorted and distinct"; return CSV_EINVAL; }
+    int rc = split_order_begin(ctx, n_contigs, shards, min_mapq, (int64_t)n_supp);
+    if (rc) return rc;
+    rc = split_order_finish(ctx, supp_hash, n_supp, out_rec, capacity, out_off);
+    if (rc) { delete ctx->split_state; ctx->split_state = nullptr; }         // (one call: nothing is kept for a retry, the caller repeats it with the size from out_off)
+    return rc;
 }
 
 int csvgpu_window_log2_resident(csv_ctx *ctx, csv_shard *sh, const uint32_t *region_start, const uint32_t *region_end,

@@ -197,6 +197,10 @@ void SplitPass::Impl::prepare()
     // Contigs whose names are known to be unique can get the map's iteration order from params.device_order (the device): for them
     // only the supplementary records are collected here and the primaries counted.
     auto on_device = [&](size_t c) { return params.device_order && contigs[c].unique_names; };
+    // the device's share starts now: the part of it that needs no supplementary record runs beside the collection below
+    std::vector<size_t> dev_contigs;
+    for (size_t c = 0; c < contigs.size(); c++) if (on_device(c) && contigs[c].n) dev_contigs.push_back(c);
+    if (!dev_contigs.empty()) params.device_order->begin(dev_contigs, params.min_mapq);
     std::unique_ptr<csvhost::TraceScope> tr(new csvhost::TraceScope("split: collect"));
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         const size_t c = by_size[k];
@@ -238,8 +242,6 @@ void SplitPass::Impl::prepare()
 
     // ---- the device's share: which primaries have a supplementary record's name hash, in the map's iteration order ----------------
     tr.reset(new csvhost::TraceScope("split: device order"));
-    std::vector<size_t> dev_contigs;
-    for (size_t c = 0; c < contigs.size(); c++) if (on_device(c) && work[c].n_primary) dev_contigs.push_back(c);
     if (!dev_contigs.empty()) {
         std::vector<uint64_t> supp_hash;
         supp_hash.reserve(supp_index.size());

@@ -46,6 +46,9 @@ struct SplitOrderSource {
     // which[k] indexes the `contigs` vector of findSplitSVSignatures; recs[k] = record indices of contig which[k]'s primaries whose name
     // hash is in supp_hash (sorted, distinct), in iteration order. Only asked for contigs with SplitContig::unique_names.
     virtual void survivors(const std::vector<size_t> &which, int min_mapq, const std::vector<uint64_t> &supp_hash, std::vector<std::vector<uint32_t>> &recs) const = 0;
+    // Optional head start: called with the same `which` before the supplementary records have been collected, so that whatever does not
+    // depend on them (on the device: the nodes and all but the last epochs of every map, csvgpu_split_order_begin) runs meanwhile.
+    virtual void begin(const std::vector<size_t> &which, int min_mapq) const { (void)which; (void)min_mapq; }
 };
 
 struct SplitParams {

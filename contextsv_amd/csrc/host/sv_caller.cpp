@@ -366,9 +366,33 @@ struct ShardIntervals : IntervalSource {
 // shard of split-pass contig c (its query-name hashes were attached when it was staged)
 struct ShardOrderSource : SplitOrderSource {
     ShardOrderSource(csv_ctx *ctx, std::vector<csv_shard *> shard_of) : ctx(ctx), shard_of(std::move(shard_of)) {}
+    void begin(const std::vector<size_t> &which, int min_mapq) const override
+    {
+        pending.clear();
+        if (which.empty() || which.size() > 32) return;                           // (more than one batch: the one-call form below)
+        std::vector<csv_shard *> sh(which.size());
+        for (size_t k = 0; k < which.size(); k++) sh[k] = shard_of[which[k]];
+        check(ctx, csvgpu_split_order_begin(ctx, (int)sh.size(), sh.data(), (uint8_t)min_mapq), "split-read order (begin)");
+        pending = which; pending_mapq = min_mapq;
+    }
     void survivors(const std::vector<size_t> &which, int min_mapq, const std::vector<uint64_t> &supp_hash, std::vector<std::vector<uint32_t>> &recs) const override
     {
         recs.assign(which.size(), {});
+        if (!pending.empty() && pending == which && pending_mapq == min_mapq) {      // the head start was taken: only the last epochs are left
+            pending.clear();
+            const size_t nb = which.size();
+            std::vector<uint64_t> off(nb + 1, 0);
+            std::vector<uint32_t> out(std::max<size_t>(supp_hash.size() * 2, 1024));
+            int rc = csvgpu_split_order_finish(ctx, supp_hash.data(), supp_hash.size(), out.data(), out.size(), off.data());
+            if (rc == CSV_ECAPACITY) {
+                out.resize(off[nb]);
+                rc = csvgpu_split_order_finish(ctx, supp_hash.data(), supp_hash.size(), out.data(), out.size(), off.data());
+            }
+            check(ctx, rc, "split-read order");
+            for (size_t k = 0; k < nb; k++) recs[k].assign(out.begin() + (std::ptrdiff_t)off[k], out.begin() + (std::ptrdiff_t)off[k + 1]);
+            return;
+        }
+        pending.clear();
         for (size_t b0 = 0; b0 < which.size(); b0 += 32) {                       // the entry point takes up to 32 contigs per call
             const size_t nb = std::min<size_t>(32, which.size() - b0);
             std::vector<csv_shard *> sh(nb);
@@ -386,6 +410,8 @@ struct ShardOrderSource : SplitOrderSource {
     }
     csv_ctx *ctx;
     std::vector<csv_shard *> shard_of;
+    mutable std::vector<size_t> pending;          // the contigs csvgpu_split_order_begin was called for, until _finish
+    mutable int pending_mapq = 0;
 };
 
 }  // namespace

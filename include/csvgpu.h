@@ -312,6 +312,13 @@ int csvgpu_shard_set_qname_hash(csv_ctx *ctx, csv_shard *shard, const uint64_t *
  * (host/umap_order.h) has to be used for that contig. CSV_ECAPACITY: out_rec too small, out_off[n_contigs] holds the required count. */
 int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq, const uint64_t *supp_hash, uint64_t n_supp,
                        uint32_t *out_rec, uint64_t capacity, uint64_t *out_off);
+/* The same in two calls, so that the part that needs no supplementary record — the nodes and all but the last epochs of every contig's map:
+ * most of the device's work — runs while the caller is still collecting the supplementary records (sv_caller.cpp:146-165 does both in one loop
+ * over the file). _begin queues that work on the context's stream and returns; _finish takes the hashes and returns what csvgpu_split_order
+ * returns. No other entry point may be called on this context between the two (they share its workspaces); one pending order per context;
+ * after CSV_ECAPACITY _finish may be called again with a larger out_rec. */
+int csvgpu_split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq);
+int csvgpu_split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t n_supp, uint32_t *out_rec, uint64_t capacity, uint64_t *out_off);
 
 /* csvgpu_window_log2 on the depth map that the last csvgpu_chr_pipeline_dev() left resident in `shard`
  * (region tables and outputs are host memory; the depth map never leaves HBM). */

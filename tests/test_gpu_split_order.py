@@ -65,6 +65,8 @@ def test_split_order_against_a_real_unordered_map(ctx, sizes, supp_frac, tail):
             supp_names += [names[i] for i in prim[has_supp]] + ["ghost%d_%d" % (t, k) for k in range(3)]
         supp_hash = np.unique(host.string_hashes(supp_names))
         got = ctx.split_order(shards, 20, supp_hash)
+        two = ctx.split_order_two_calls(shards, 20, supp_hash)             # _begin before the supplementary records are known, _finish (with a retry)
+        assert all(np.array_equal(a, b) for a, b in zip(got, two))
         for t, (names, prim, has_supp) in enumerate(per):
             keys = [names[i] for i in prim]
             order_real, order_emu, buckets = host.umap_order_check(keys, (~has_supp).astype(np.uint8))
