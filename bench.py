@@ -23,6 +23,7 @@ Legs reported beside the headline at N = 1: `chr22_cigar_path` (BASELINE configs
 `cpu_baseline` (the CPU restatement on the same 24 contigs, one contig per thread as the reference schedules them, on a stated sample).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -44,6 +45,14 @@ REC_I32 = 12                   # one merged call record = 48 B (host.CALL_DTYPE)
 
 def seed_of(config, contig):
     return 0x5EED0000 + 1000 * config + contig + 1
+
+
+def call_digest(tid, calls):
+    """SHA-256 of a run's merged call records (48 B each, contig after contig in the run's order) with their contig ids."""
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(tid).tobytes())
+    h.update(np.ascontiguousarray(calls).tobytes())
+    return h.hexdigest()
 
 
 def main():
@@ -68,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only (no chr22 / chr1 / from-file legs)")
     ap.add_argument("--no-from-file", action="store_true")
+    ap.add_argument("--no-hifi-leg", action="store_true", help="skip the 60x HiFi whole-genome leg (BASELINE.json configs[4] on this rank's GPU)")
     ap.add_argument("--cpu-sample-frac", type=float, default=0.25, help="leading fraction of every contig's reads given to the CPU baseline")
     ap.add_argument("--verify-against-single", action="store_true", help="rank 0 also stages the WHOLE genome, runs it alone and asserts that the gathered "
                     "call set of the sharded run is byte-identical (rehearsals / tests; costs rank 0 the whole staging)")
@@ -121,7 +131,7 @@ def main():
     for c in lane_ctx:
         c.set_gate(gate)
 
-    def stage(contig_ids, keep_sample):
+    def stage(contig_ids, keep_sample, tech=tech, depth=args.depth, config_id=config_id):
         """Generate, upload and free one contig at a time -> (Genome, per-contig info, CPU-baseline samples)."""
         g = host.Genome()
         info, samples = [], []
@@ -129,7 +139,7 @@ def main():
         h2d = 0
         for k in contig_ids:
             t0 = time.perf_counter()
-            syn = host.SynthShard(seed_of(config_id, k), lens[k], args.depth, tech, gen_threads)
+            syn = host.SynthShard(seed_of(config_id, k), lens[k], depth, tech, gen_threads)
             t1 = time.perf_counter()
             g.add_synth(ctx, NAMES[k], k, syn, snp_seed=seed_of(config_id, k), with_snps=True)
             t2 = time.perf_counter()
@@ -274,6 +284,8 @@ def main():
                        "parallelism": f"chromosome-shard x{world}", "lanes": n_lanes, "scale": args.scale},
             "signatures_clustered_per_s": sigs_all * K / elapsed,
             "cigar_ops_per_s": ops_all * K / elapsed,
+            "call_set_sha256": (call_digest(tid, calls) if world == 1 else
+                                call_digest(np.concatenate([np.full(len(gathered[k]), k, np.int32) for k in sorted(gathered)]), np.concatenate([gathered[k] for k in sorted(gathered)]))),
             "stage_ms_per_step_rank0": {k: round(v, 3) for k, v in stage_ms.items()},
             "stage_counts_rank0": counts,
             "kernel_ms_per_step_rank0": {k: round(v, 4) for k, v in kern.items()},
@@ -297,8 +309,11 @@ def main():
             k2 = max(3, min(K, 10))
             t0 = time.perf_counter()
             for _ in range(k2):
-                genome.run(ctx, hmm, lanes=lane_ctx, eps=args.eps, min_pts_pct=args.min_pts_pct, host_threads=args.host_threads, capacity=cap, overlap_split=False)
+                c2, t2, _, _ = genome.run(ctx, hmm, lanes=lane_ctx, eps=args.eps, min_pts_pct=args.min_pts_pct, host_threads=args.host_threads, capacity=cap, overlap_split=False)
             ctx.synchronize()
+            # the timed steps take the early batches inside the CIGAR pass (timing-dependent batch sizes), this leg takes none: same calls or the run fails
+            if call_digest(t2, c2) != out["call_set_sha256"]:
+                raise SystemExit("bench.py: the call set of the overlapped step differs from the step without the split overlap")
             el2 = time.perf_counter() - t0
             tm2 = {}
             for c in lane_ctx:
@@ -306,7 +321,7 @@ def main():
                     a = tm2.get(kk, (0.0, 0)); tm2[kk] = (a[0] + ms, a[1] + n)
                 c.timing_enable(0)
             d_ms = tm2.get(dominant, (0.0, 0))[0] / k2
-            out["no_split_overlap"] = {"value": reads_all * k2 / el2, "unit": "reads/s", "ms_per_step": el2 / k2 * 1e3, "steps": k2,
+            out["no_split_overlap"] = {"call_set_equal": True, "value": reads_all * k2 / el2, "unit": "reads/s", "ms_per_step": el2 / k2 * 1e3, "steps": k2,
                                        "kernel_ms_per_step": {kk: round(v[0] / k2, 4) for kk, v in tm2.items() if v[1]},
                                        "roofline_frac": (alg_bytes[dominant] / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if d_ms > 0 else None,
                                        "note": "the split-read pass's ordering kernels after the CIGAR pass instead of beside it: the big kernels have the device to "
@@ -323,6 +338,8 @@ def main():
             out["chr22_cigar_path"] = leg_chr22(cs, host, dev, args, tech, config_id, gen_threads)
             if not args.no_from_file:
                 out["from_file"] = from_file(cs, host, ctx, args, tech, config_id, gen_threads)
+        if world == 1 and not args.no_legs and tech == 0 and not args.no_hifi_leg:
+            out["hifi_wgs"] = leg_hifi_wgs(stage, ctx, lane_ctx, hmm, args, n_contigs, cap)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(samples, args, reads_all)
         print(json.dumps(out), flush=True)
@@ -337,6 +354,57 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def leg_hifi_wgs(stage, ctx, lane_ctx, hmm, args, n_contigs, cap):
+    """BASELINE configs[4]'s workload on one GPU: the same 24 contig lengths at 60x synthetic PacBio HiFi (1.04e7 reads of ~37 CIGAR ops:
+    ten times the reads of the ONT genome in a twentieth of the CIGAR words) through the same step. The scan and the depth walk take their
+    short-read forms here (groups of 16 lanes per read, chosen per shard from the mean CIGAR words per read: scan.hip, depth.hip)."""
+    from contextsv_amd import host
+    g, info, _, staging = stage(list(range(n_contigs)), False, tech=1, depth=60.0, config_id=4)
+    try:
+        reads = sum(i["reads"] for i in info)
+        ops = sum(i["cigar_ops"] for i in info)
+        run = lambda: g.run(ctx, hmm, lanes=lane_ctx, eps=args.eps, min_pts_pct=args.min_pts_pct, host_threads=args.host_threads, capacity=cap)
+        for _ in range(2):
+            run()
+        for c in lane_ctx or [ctx]:
+            c.timing_enable(3); c.timing_reset()
+        if lane_ctx:
+            ctx.timing_enable(1); ctx.timing_reset()
+        steps = max(3, min(args.steps, 10))
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        acc = None
+        for _ in range(steps):
+            calls, tid, st, per = run()
+            vals = [getattr(st, f) for f, _ in host.stage_times._fields_]
+            acc = vals if acc is None else [a + b for a, b in zip(acc, vals)]
+        ctx.synchronize()
+        el = time.perf_counter() - t0
+        tm = {}
+        for c in (lane_ctx or []) + [ctx]:
+            for k, (ms, n) in c.timing().items():
+                a = tm.get(k, (0.0, 0)); tm[k] = (a[0] + ms, a[1] + n)
+            c.timing_enable(0)
+        kern = {k: v[0] / steps for k, v in tm.items() if v[1]}
+        n_sig = sum(p.n_signatures for p in per)
+        b_scan = 4.0 * ops + 23.0 * reads + 16.0 * n_sig
+        b_depth = 4.0 * ops + 4.0 * sum(i["len"] + 1 for i in info)
+        stage_ms = {f: round(v / steps, 3) for (f, _), v in zip(host.stage_times._fields_, acc) if f.startswith("ms_")}
+        return {"workload": f"whole genome, {n_contigs} contigs, 60x synthetic HiFi, resident; same step (BASELINE.json configs[4] on one GPU)",
+                "value": reads * steps / el, "unit": "reads/s", "ms_per_step": el / steps * 1e3, "steps": steps, "reads": int(reads), "cigar_ops": int(ops),
+                "signatures": int(n_sig), "merged_calls": int(len(calls)), "signatures_clustered_per_s": n_sig * steps / el,
+                "stage_ms_per_step": stage_ms, "kernel_ms_per_step": {k: round(v, 4) for k, v in kern.items()},
+                "cigar_scan_GBps": round(b_scan / (kern["cigar_scan"] * 1e-3) / 1e9, 1) if kern.get("cigar_scan") else None,
+                "cigar_scan_frac": round(b_scan / (kern["cigar_scan"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern.get("cigar_scan") else None,
+                "depth_GBps": round(b_depth / (kern["depth"] * 1e-3) / 1e9, 1) if kern.get("depth") else None,
+                "depth_frac": round(b_depth / (kern["depth"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern.get("depth") else None,
+                "staging": staging,
+                "note": "kernel times are HIP-event times on the gate's stream inside the step (the other lanes' small kernels and the split-read pass's ordering kernels "
+                        "share the device); algorithmic bytes as for the headline: scan 4 m + 23 n + 16 n_sig, depth 4 m + 4 (L + 1)"}
+    finally:
+        g.free()
 
 
 def leg_chr1(cs, host, ctx, lane_ctx, genome, info, hmm, args):

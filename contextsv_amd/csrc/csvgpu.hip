@@ -393,7 +393,9 @@ static csv_ctx *create_ctx(int device_ordinal, void *stream, int low_priority)
     else {
         int least = 0, greatest = 0;
         if (low_priority) (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const hipError_t se = low_priority ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        const char *pe = getenv("CSV_BG_PRIORITY");                    // experiments: "high" turns the background context into a foreground one
+        const int prio = (pe && pe[0] == 'h') ? greatest : least;
+        const hipError_t se = low_priority ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete ctx; return nullptr; }
         ctx->own_stream = true;
     }
