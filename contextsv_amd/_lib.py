@@ -12,7 +12,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcsvgpu.so")
+# CSVGPU_LIB: another build of the same library (tests: lib/libcsvgpu_testhooks.so, which also exports the allocation-failure hook)
+LIB_PATH = os.environ.get("CSVGPU_LIB") or os.path.join(_HERE, "lib", "libcsvgpu.so")
+ABI_VERSION = 2          # include/csvgpu.h CSVGPU_ABI_VERSION
 
 CSV_OK, CSV_EINVAL, CSV_ENODEV, CSV_ENOMEM, CSV_EHIP, CSV_ECAPACITY = 0, -1, -2, -3, -4, -5
 STATUS_NAMES = {0: "CSV_OK", -1: "CSV_EINVAL", -2: "CSV_ENODEV", -3: "CSV_ENOMEM", -4: "CSV_EHIP", -5: "CSV_ECAPACITY"}
@@ -76,7 +78,6 @@ ABI = {
     "csvgpu_chr_job_cluster": (C.c_int, [_P, _P, C.c_double, _P, _P, C.c_uint64]),
     "csvgpu_chr_job_end": (C.c_int, [_P, _P, C.POINTER(csv_chr_result)]),
     "csvgpu_chr_job_abort": (C.c_int, [_P, _P]),
-    "csvgpu_test_fail_next_alloc": (None, [C.c_int]),
     "csvgpu_gate_create": (_P, []),
     "csvgpu_gate_destroy": (None, [_P]),
     "csvgpu_set_gate": (C.c_int, [_P, _P]),
@@ -116,6 +117,12 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, which must be loud
         fn.restype = res
         fn.argtypes = args
+    got = lib.csvgpu_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {got}, this package expects {ABI_VERSION}: rebuild (__graft_entry__.build())")
+    if hasattr(lib, "csvgpu_test_fail_next_alloc"):          # only in the test build (libcsvgpu_testhooks.so via CSVGPU_LIB)
+        lib.csvgpu_test_fail_next_alloc.restype = None
+        lib.csvgpu_test_fail_next_alloc.argtypes = [C.c_int]
     _lib = lib
     return lib
 

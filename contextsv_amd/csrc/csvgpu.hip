@@ -1,5 +1,6 @@
 // csvgpu.hip — implementation of the C-ABI in include/csvgpu.h: context, staging, kernel chains.
 // No CPU fallback lives here: every result is produced by the kernels under kernels/.
+#include <atomic>
 #include <string.h>
 
 #include <algorithm>
@@ -12,8 +13,18 @@
 namespace csv {
 
 static std::string g_create_err;
-int g_fail_alloc = 0;                                  // csvgpu_test_fail_next_alloc
-static inline bool csv_test_fail_alloc() { if (g_fail_alloc > 0) { g_fail_alloc--; return true; } return false; }
+#ifdef CSV_TEST_HOOKS
+// csvgpu_test_fail_next_alloc — only in the test build of the library (libcsvgpu_testhooks.so: Makefile), never in libcsvgpu.so
+static std::atomic<int> g_fail_alloc{0};
+static inline bool csv_test_fail_alloc()
+{
+    int n = g_fail_alloc.load();
+    while (n > 0) if (g_fail_alloc.compare_exchange_weak(n, n - 1)) return true;
+    return false;
+}
+#else
+static inline bool csv_test_fail_alloc() { return false; }
+#endif
 
 int arena_reserve(csv_ctx *ctx, Arena &a, size_t bytes)
 {
@@ -1771,8 +1782,10 @@ int csvgpu_chr_job_abort(csv_ctx *ctx, csv_job *job)
     return CSV_OK;
 }
 
-// Test hook (CPU-side error-path tests): the next n device allocations guarded by csv_test_fail_alloc() fail.
-void csvgpu_test_fail_next_alloc(int n) { csv::g_fail_alloc = n; }
+#ifdef CSV_TEST_HOOKS
+// Test hook (error-path tests): the next n device allocations guarded by csv_test_fail_alloc() fail.
+void csvgpu_test_fail_next_alloc(int n) { csv::g_fail_alloc.store(n); }
+#endif
 
 static int chr_pipeline(csv_ctx *ctx, csv_shard *sh, uint32_t min_oplen, uint8_t min_mapq, double eps, double min_pts_pct, csv_chr_result *res,
                         csv_sig *host_sig, int32_t *host_labels, uint64_t capacity)

@@ -185,6 +185,7 @@ bool BamReader::loadIndex(const std::string &index_path)
     auto idx = std::make_unique<Index>();
     const uint32_t n_ref = le32(p + 4);
     size_t o = 8;
+    if ((uint64_t)n_ref * 8 > n - 8) { err = "BAI: truncated"; return false; }      // (every reference has at least its two counts: found by tools/fuzz — a flipped count asked for 2^32 entries)
     idx->refs.resize(n_ref);
     for (uint32_t r = 0; r < n_ref; r++) {
         if (o + 4 > n) { err = "BAI: truncated"; return false; }
@@ -373,7 +374,9 @@ bool BamReader::readContig(const std::string &chr, const BamReadOptions &opt, Ba
     if ((size_t)tid >= index->refs.size() || !index->refs[tid].any) return true;
     const Index::Ref &ref = index->refs[tid];
     // size the big arrays once: the contig's compressed span bounds its records (BGZF rarely expands; CIGAR words dominate)
-    const uint64_t span = ((ref.max_end >> 16) - (ref.min_beg >> 16)) + bgzf::kMaxBlock;
+    // (offsets come from the index file: a corrupt one must not size an allocation — found by tools/fuzz)
+    if ((ref.max_end >> 16) < (ref.min_beg >> 16) || (ref.min_beg >> 16) > file.size()) { err = "BAI: chunk offsets outside " + path; return false; }
+    const uint64_t span = std::min<uint64_t>((ref.max_end >> 16) - (ref.min_beg >> 16), file.size()) + bgzf::kMaxBlock;
     out.cigar.reserve((size_t)(span * 4 / 4));            // ~4x compression of CIGAR words is typical; growth is by mremap anyway
     const int64_t end = hdr.lens[tid];
     return stream(ref.min_beg, opt, [&](const RecRef *recs, size_t n) -> size_t {

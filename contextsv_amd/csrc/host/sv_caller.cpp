@@ -309,7 +309,7 @@ std::vector<int> SVCaller::assignShards(const std::vector<double> &weights, int 
 
 void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double eps, double pct,
                                     std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats,
-                                    const std::function<void(size_t lane, size_t k)> &on_merged)
+                                    const std::function<void(size_t lane, size_t k)> &on_merged, int min_mapq, int min_oplen)
 {
     calls.assign(lanes.size(), {});
     stats.assign(lanes.size(), {});
@@ -320,6 +320,7 @@ void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqSto
         threads.push_back(pool.start([&, l] {
             try {
                 SVCaller caller(lanes[l].ctx);
+                caller.min_mapq = min_mapq; caller.min_oplen = min_oplen;
                 if (on_merged) caller.on_merged = [&on_merged, l](size_t k) { on_merged(l, k); };
                 if (!lanes[l].seqs.empty()) caller.processResidentChromosomesPipelined(lanes[l].shards, lanes[l].seqs, eps, pct, calls[l], stats[l]);
                 else caller.processResidentChromosomesPipelined(lanes[l].shards, seq, eps, pct, calls[l], stats[l]);
@@ -518,6 +519,13 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     csvhost::set_context(ctx);
     const double t_begin = now_ms();
     RunStageTimes T;
+    // The caller's own context works on another thread while the lanes run the CIGAR pass (split-read prepare, csvgpu_split_order, the early
+    // copy-number batches): a context is one arena + one stream + one set of timers and belongs to one thread at a time.
+    for (csv_ctx *lc : lane_ctxs)
+        if (lc == ctx) throw std::invalid_argument("runResident: the caller's context must not be one of the lanes (each lane needs a context of its own)");
+    for (size_t a = 0; a < lane_ctxs.size(); a++)
+        for (size_t b = 0; b < a; b++)
+            if (lane_ctxs[a] == lane_ctxs[b]) throw std::invalid_argument("runResident: the same context given for two lanes");
     std::vector<ResidentContig> contigs = contigs_in;
     const size_t n = contigs.size();
     std::vector<ChrStats> stats(n);
@@ -592,7 +600,10 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                         // (a batch takes a few milliseconds beside the pass: with fewer than eight contigs still to come the pass could be
                         // over first and the run would wait for the batch — those go with the rest, behind the pass; a rank with a handful of
                         // contigs never takes one)
-                        if (unmerged < 8 && !env_on("CSV_EARLY_CN_WAIT_ALL")) break;
+                        // (CSV_EARLY_SMALL_BATCHES: tests — a batch whenever three more contigs are merged, down to the last one)
+                        const bool small_batches = env_on("CSV_EARLY_SMALL_BATCHES");
+                        if (unmerged < 8 && !env_on("CSV_EARLY_CN_WAIT_ALL") && !small_batches) break;
+                        if (small_batches && first && snap.size() < 3 && !over) { std::this_thread::sleep_for(std::chrono::microseconds(100)); continue; }
                         if (!first && (over || snap.size() < 3)) {
                             if (over) break;
                             std::this_thread::sleep_for(std::chrono::microseconds(100));
@@ -688,7 +699,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         } else {
             std::function<void(size_t, size_t)> note;
             if (early_cn) note = [&early](size_t l, size_t k) { std::lock_guard<std::mutex> g(early.mu); early.merged.emplace_back(l, k); };
-            processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats, note);
+            processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats, note, min_mapq, min_oplen);
         }
         T.ms_cigar = now_ms() - t_begin;
         { std::lock_guard<std::mutex> l(early.mu); early.pass_over = true; }

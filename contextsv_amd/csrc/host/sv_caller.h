@@ -144,7 +144,7 @@ public:
 
     static void processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double dbscan_epsilon, double dbscan_min_pts_pct,
                                      std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats,
-                                     const std::function<void(size_t lane, size_t k)> &on_merged = {});
+                                     const std::function<void(size_t lane, size_t k)> &on_merged = {}, int min_mapq = 20, int min_oplen = 50);
     // called by processResidentChromosomesPipelined's merge threads when shard i's calls and statistics are final (any thread; may be empty)
     std::function<void(size_t)> on_merged;
 

@@ -10,7 +10,8 @@ import numpy as np
 from . import _lib
 from .context import Context, Reads, Shard
 
-HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcontextsv_host.so")
+# CONTEXTSV_HOST_LIB: another build of the host mirror (tests: the AddressSanitizer build, csrc/_obj/libcontextsv_host_asan.so)
+HOST_LIB_PATH = os.environ.get("CONTEXTSV_HOST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcontextsv_host.so")
 
 CALL_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("sv_type", "<i4"), ("cluster_size", "<i4"), ("hmm_likelihood", "<f8"),
                        ("id", "<i8"), ("aln_flags", "<u4"), ("genotype", "<i4"), ("cn_state", "<i4"), ("aln_offset", "<i4")])

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSVGPU_ABI_VERSION 1
+#define CSVGPU_ABI_VERSION 2   /* 2: CSV_K_SPLIT_ORDER, csvgpu_split_order_begin / _finish, the job / gate / batch entry points; the test hook left the product library */
 
 typedef struct csv_ctx csv_ctx;
 
@@ -357,9 +357,11 @@ int csvgpu_viterbi_dev(csv_ctx *ctx, const csv_hmm *hmm, const double *d_o1, con
                        const double *d_pfb, const uint64_t *d_seq_off, uint64_t n_seq,
                        uint64_t n_obs, int32_t *d_states, double *d_loglik);
 
-/* Test hook: the next n guarded device allocations inside the library fail as if HBM were exhausted (error-path tests of the
- * signature-buffer growth in csvgpu_chr_job_cluster). Not for production callers. */
+#ifdef CSV_TEST_HOOKS
+/* Test build only (libcsvgpu_testhooks.so, -DCSV_TEST_HOOKS; libcsvgpu.so does not export it): the next n guarded device allocations
+ * inside the library fail as if HBM were exhausted (error-path tests of the signature-buffer growth in csvgpu_chr_job_cluster). */
 void csvgpu_test_fail_next_alloc(int n);
+#endif
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "csvgpu.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef CSV_TEST_HOOKS.*?#endif", "", text, flags=re.S)          # the test build's hook is not part of the product ABI
     return sorted(set(re.findall(r"\b(csvgpu_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -23,7 +24,8 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/csvgpu.h but not exported"
     assert sorted(_lib.ABI) == names, "ctypes table and header disagree"
-    assert lib.csvgpu_abi_version() == 1
+    assert lib.csvgpu_abi_version() == _lib.ABI_VERSION == 2
+    assert not hasattr(lib, "csvgpu_test_fail_next_alloc"), "the allocation-failure hook must not be in the product library"
 
 
 def test_struct_layouts_match_header():
@@ -52,3 +54,14 @@ def test_product_package_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hpp", ".hip")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "libcsvoracle" not in txt and "oracle_lib" not in txt and "csv_oracle" not in txt, os.path.join(dp, f)
+
+
+def test_testhooks_build_exports_the_same_abi_plus_the_hook():
+    """libcsvgpu_testhooks.so (csvgpu.hip with -DCSV_TEST_HOOKS; loaded only by tests/test_gpu_job_errors.py) = the product ABI + the hook."""
+    from contextsv_amd import _lib
+    lib = C.CDLL(os.path.join(ROOT, "contextsv_amd", "lib", "libcsvgpu_testhooks.so"))
+    for n in _declared():
+        assert hasattr(lib, n), n
+    assert hasattr(lib, "csvgpu_test_fail_next_alloc")
+    lib.csvgpu_abi_version.restype = C.c_int
+    assert lib.csvgpu_abi_version() == _lib.ABI_VERSION

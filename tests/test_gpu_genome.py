@@ -101,3 +101,76 @@ def test_resident_run_on_generated_shards_equals_oracle_chain(ctx, oracle, tech,
     if tech == 0:
         assert st.n_split_calls > 0
     g.free()
+
+
+def _many_small(ctx, n_contigs=14, tech=0, depth=20.0):
+    g = host.Genome()
+    for t in range(n_contigs):
+        L = 300_000 + 37_000 * (t % 5)
+        syn = host.SynthShard(0xBEEF00 + 31 * t + tech, L, depth, tech, 2, sv_per_bp=1.0 / 20000.0)
+        r = syn.reads
+        reads = cs.Reads(r.pos.copy(), r.flag.copy(), r.mapq.copy(), r.cigar_off.copy(), r.cigar.copy())
+        qid = syn.qname_id.astype(np.uint32) + np.uint32(t << 24)
+        rng = np.random.default_rng(100 + t)
+        n_snp = L // 1000
+        pos = np.sort(rng.choice(np.arange(1000, L - 1000), n_snp, replace=False)).astype(np.uint32)
+        snps = {"pos": pos, "baf": np.where(rng.random(n_snp) < 0.66, 0.45 + 0.1 * rng.random(n_snp), 1.0), "pfb": np.zeros(n_snp), "has_pfb": np.zeros(n_snp, np.uint8)}
+        g.add(ctx, "contig%d" % t, t, reads, syn.depth_len, qid, snps, name_style=0)
+        syn.free()
+    return g
+
+
+def test_early_batches_inside_the_pass_give_the_same_calls(ctx):
+    """The production path of the 24-contig step: with eight or more contigs still to come, the copy-number predictions, the split-read
+    chain and the merges of the contigs merged so far are made in batches INSIDE the CIGAR pass (SVCaller::runResident). Fourteen small
+    contigs through three lanes: the default run (batch sizes depend on timing), batches of three down to the last contig
+    (CSV_EARLY_SMALL_BATCHES), one batch of everything (CSV_EARLY_CN_WAIT_ALL), no early batch at all (CSV_NO_EARLY_CN), no split overlap,
+    and the run without lanes must give the same records."""
+    import os
+    hmm = make_hmm(**WGS_HMM)
+    host.set_context(ctx)
+    g = _many_small(ctx)
+    lanes = [cs.Context(0) for _ in range(3)]
+    gate = cs.Gate()
+    try:
+        for c in lanes:
+            c.set_gate(gate)
+        ref, ref_tid, st0, _ = g.run(ctx, hmm)                                     # no lanes: nothing early
+        assert len(ref) > 20 and st0.n_cigar_cn_regions > 0 and st0.n_split_calls > 0
+        for env, kw in (({}, {}), ({"CSV_EARLY_SMALL_BATCHES": "1"}, {}), ({"CSV_EARLY_CN_WAIT_ALL": "1"}, {}), ({"CSV_NO_EARLY_CN": "1"}, {}),
+                        ({"CSV_NO_EARLY_SPLIT": "1", "CSV_EARLY_SMALL_BATCHES": "1"}, {}), ({}, {"overlap_split": False})):
+            os.environ.update(env)
+            try:
+                for _ in range(2):
+                    got, tid, st, _ = g.run(ctx, hmm, lanes=lanes, **kw)
+                    assert np.array_equal(tid, ref_tid), env
+                    _same(got, ref)
+                    assert st.n_cigar_cn_regions == st0.n_cigar_cn_regions and st.n_split_calls == st0.n_split_calls
+            finally:
+                for k in env:
+                    del os.environ[k]
+    finally:
+        for c in lanes:
+            c.set_gate(None)
+            c.close()
+        gate.close()
+        g.free()
+
+
+def test_the_callers_context_cannot_be_a_lane(ctx):
+    """runResident works on the caller's context from another thread while the lanes run the CIGAR pass: a context handed in as a lane too
+    (or twice) would be driven by two threads — refused."""
+    hmm = make_hmm(**WGS_HMM)
+    host.set_context(ctx)
+    g = _many_small(ctx, n_contigs=2)
+    other = cs.Context(0)
+    try:
+        with pytest.raises(Exception):
+            g.run(ctx, hmm, lanes=[ctx, other])
+        with pytest.raises(Exception):
+            g.run(ctx, hmm, lanes=[other, other])
+        got, tid, _, _ = g.run(ctx, hmm, lanes=[other])                            # (still usable afterwards)
+        assert len(tid) == len(got)
+    finally:
+        other.close()
+        g.free()
