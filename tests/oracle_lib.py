@@ -136,6 +136,17 @@ class Oracle:
         self.lib.orc_dbscan_iv(_p(start), _p(end), len(start), eps, min_pts, _p(lab))
         return lab[: len(start)]
 
+    def dbscan_iv_windowed(self, start, end, eps, min_pts):
+        """oracle/dbscan_window.cpp: the order-free windowed form, O(n * window) — pinned against the reference in tests/test_oracle_windowed.py"""
+        start = np.ascontiguousarray(start, np.uint32); end = np.ascontiguousarray(end, np.uint32)
+        lab = np.zeros(max(len(start), 1), np.int32)
+        self.lib.orc_dbscan_iv_windowed.restype = C.c_int
+        self.lib.orc_dbscan_iv_windowed.argtypes = [P, P, C.c_uint64, C.c_double, C.c_int32, P]
+        rc = self.lib.orc_dbscan_iv_windowed(_p(start), _p(end), len(start), eps, min_pts, _p(lab))
+        if rc:
+            raise ValueError("orc_dbscan_iv_windowed: eps outside [0, 1)")
+        return lab[: len(start)]
+
     def dbscan_1d(self, pts, eps, min_pts):
         pts = np.ascontiguousarray(pts, np.int32)
         lab = np.zeros(max(len(pts), 1), np.int32)

@@ -174,3 +174,45 @@ def test_the_callers_context_cannot_be_a_lane(ctx):
     finally:
         other.close()
         g.free()
+
+
+def test_three_largest_contigs_at_full_size_batched_equals_per_contig(ctx):
+    """The genome-wide batching of the benchmark's step at SIZE: chr1 + chr2 + chr3 of the 30x ONT genome (1.6e6 reads, 7.5 GB of CIGAR
+    words) resident together and run through three lanes — one Viterbi / DBSCAN1D / small-set DBSCAN launch over all contigs, the split
+    order of all contigs in one chain, early batches under timing — must give, contig by contig, exactly the records of each contig run
+    ALONE on one context (the per-contig path whose scan / depth / labels / merged calls meet the oracle at this size in
+    tests/test_gpu_configs.py)."""
+    import hashlib
+    GRCH38 = [248956422, 242193529, 198295559]
+    hmm = make_hmm(**WGS_HMM)
+    host.set_context(ctx)
+    lanes = [cs.Context(0) for _ in range(3)]
+    gate = cs.Gate()
+    g = host.Genome()
+    singles = []
+    try:
+        for c in lanes:
+            c.set_gate(gate)
+        for k, L in enumerate(GRCH38):
+            syn = host.SynthShard(0x5EED0000 + 3000 + k + 1, L, 30.0, 0, 16)
+            g.add_synth(ctx, "chr%d" % (k + 1), k, syn, snp_seed=0x5EED0000 + 3000 + k + 1, with_snps=True)
+            one = host.Genome()
+            one.add_synth(ctx, "chr%d" % (k + 1), k, syn, snp_seed=0x5EED0000 + 3000 + k + 1, with_snps=True)
+            syn.free()
+            calls1, tid1, st1, _ = one.run(ctx, hmm, capacity=1 << 18)
+            singles.append((np.ascontiguousarray(calls1).tobytes(), len(calls1), st1.n_cigar_cn_regions, st1.n_split_calls))
+            one.free()
+        for rep in range(2):
+            calls, tid, st, per = g.run(ctx, hmm, lanes=lanes, capacity=1 << 18)
+            assert st.n_reads > 1_500_000 and len(calls) > 5000
+            for k in range(3):
+                mine = np.ascontiguousarray(calls[tid == k])
+                assert len(mine) == singles[k][1], (rep, k)
+                assert hashlib.sha256(mine.tobytes()).hexdigest() == hashlib.sha256(singles[k][0]).hexdigest(), (rep, k)
+            assert st.n_cigar_cn_regions == sum(s[2] for s in singles) and st.n_split_calls == sum(s[3] for s in singles)
+    finally:
+        for c in lanes:
+            c.set_gate(None)
+            c.close()
+        gate.close()
+        g.free()
