@@ -157,16 +157,85 @@ void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t 
         if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) dst.push_back(toSVCall(sig[base + i], seq));
         else mergeSignaturesWithLabels(sig + base, labels + base, type_n[t], seq, dst);
     };
-    if (n_del >= 20000 && n_ins >= 20000) {
-        // a large contig's two types side by side when the host pool is free (a rank that holds chr1 alone waits 2.5 ms for this merge;
-        // in a whole-genome pass the lanes' other merges hide it and the pool is usually taken: then the two run one after the other here)
-        std::vector<SVCall> ins_calls;
-        csvhost::parallel_for(2, 2, [&](size_t t) { one_type((int)t, t ? ins_calls : chr_sv_calls); });
-        chr_sv_calls.insert(chr_sv_calls.end(), std::make_move_iterator(ins_calls.begin()), std::make_move_iterator(ins_calls.end()));
-    } else {
+    if (n_sig < 40000) {
         one_type(0, chr_sv_calls);
         one_type(1, chr_sv_calls);
+        return;
     }
+    // (a type with few signatures — the deletions of a synthetic ONT contig — goes through the sequential form, the other through the sections)
+    const bool big[2] = {n_del >= 20000, n_ins >= 20000};
+    // A large contig (a rank that holds chr1 alone waited 2.85 ms here, its device chain takes 1.9): the same bucket order and the same
+    // selections as mergeSignaturesWithLabels, in sections the host pool can share — per-chunk label counts, the members scattered chunk by
+    // chunk (a chunk's members of a label go behind the earlier chunks': input order kept), then the buckets: each type's noise bucket
+    // (93 % of the signatures; its selection is one sequential replay) as an item of its own beside ranges of clusters. When the pool is
+    // taken (a whole-genome pass: the lanes' other merges hide this one) the sections run inline, one after the other.
+    struct Ent { uint32_t len, idx; };
+    struct TypeWork {
+        uint64_t base = 0, n = 0;
+        size_t n_slots = 0;
+        std::vector<std::vector<uint32_t>> cnt;      // per chunk: members per slot, then the chunk's first position per slot
+        std::vector<uint32_t> head;
+        std::vector<Ent> member;
+        std::vector<std::vector<SVCall>> part;       // per bucket item, in slot order
+    } W[2];
+    constexpr size_t kChunks = 8;
+    for (int t = 0; t < 2; t++) { W[t].base = t ? n_del : 0; W[t].n = big[t] ? type_n[t] : 0; W[t].cnt.assign(kChunks, {}); W[t].member.resize(W[t].n); }
+    auto chunk = [&](const TypeWork &w, size_t c, uint64_t &a, uint64_t &b) { a = w.n * c / kChunks; b = w.n * (c + 1) / kChunks; };
+    csvhost::parallel_for(2 * kChunks, 0, [&](size_t it) {
+        TypeWork &w = W[it / kChunks];
+        uint64_t a, b; chunk(w, it % kChunks, a, b);
+        const int32_t *lab = labels + w.base;
+        int32_t mx = -2;
+        for (uint64_t i = a; i < b; i++) mx = std::max(mx, lab[i]);
+        std::vector<uint32_t> &c = w.cnt[it % kChunks];
+        c.assign((size_t)(mx + 3), 0);
+        for (uint64_t i = a; i < b; i++) c[(size_t)(lab[i] + 2)]++;
+    });
+    for (int t = 0; t < 2; t++) {
+        TypeWork &w = W[t];
+        for (auto &c : w.cnt) w.n_slots = std::max(w.n_slots, c.size());
+        w.head.assign(w.n_slots + 1, 0);
+        for (auto &c : w.cnt) { c.resize(w.n_slots, 0); for (size_t s2 = 0; s2 < w.n_slots; s2++) w.head[s2 + 1] += c[s2]; }
+        for (size_t s2 = 0; s2 < w.n_slots; s2++) w.head[s2 + 1] += w.head[s2];
+        std::vector<uint32_t> run(w.head.begin(), w.head.end() - 1);
+        for (auto &c : w.cnt) for (size_t s2 = 0; s2 < w.n_slots; s2++) { const uint32_t k = c[s2]; c[s2] = run[s2]; run[s2] += k; }
+    }
+    csvhost::parallel_for(2 * kChunks, 0, [&](size_t it) {
+        TypeWork &w = W[it / kChunks];
+        uint64_t a, b; chunk(w, it % kChunks, a, b);
+        const int32_t *lab = labels + w.base;
+        const csv_sig *sg = sig + w.base;
+        std::vector<uint32_t> &cur = w.cnt[it % kChunks];
+        for (uint64_t i = a; i < b; i++) w.member[cur[(size_t)(lab[i] + 2)]++] = Ent{sg[i].end - sg[i].start, (uint32_t)i};
+    });
+    // bucket items per type: [0, 1) = the noise bucket, then the clusters in kRanges ranges
+    constexpr size_t kRanges = 7;
+    for (int t = 0; t < 2; t++) W[t].part.assign(1 + kRanges, {});
+    csvhost::parallel_for(2 * (1 + kRanges), 0, [&](size_t it) {
+        TypeWork &w = W[it / (1 + kRanges)];
+        const size_t item = it % (1 + kRanges);
+        if (!big[it / (1 + kRanges)]) { if (item == 0) one_type((int)(it / (1 + kRanges)), w.part[0]); return; }
+        size_t s0 = 0, s1 = std::min<size_t>(1, w.n_slots);
+        if (item > 0) {
+            const size_t rest = w.n_slots > 1 ? w.n_slots - 1 : 0;
+            s0 = 1 + rest * (item - 1) / kRanges; s1 = 1 + rest * item / kRanges;
+        }
+        std::vector<SVCall> &dst = w.part[item];
+        const csv_sig *sg = sig + w.base;
+        for (size_t s2 = s0; s2 < s1; s2++) {
+            const size_t sz = w.head[s2 + 1] - w.head[s2];
+            if (sz < 2) continue;
+            Ent *m = w.member.data() + w.head[s2];
+            const size_t top = (size_t)std::max(1, (int)(sz * 0.2));
+            auto by_len_desc = [](const Ent &x, const Ent &y) { return x.len > y.len; };
+            const uint32_t pick = csvhost::std_sort_select(m, m + sz, (std::ptrdiff_t)(top / 2), by_len_desc)->idx;
+            SVCall rep = toSVCall(sg[pick], seq);
+            rep.cluster_size = (int)sz;
+            dst.push_back(std::move(rep));
+        }
+    });
+    for (int t = 0; t < 2; t++)
+        for (auto &v : W[t].part) chr_sv_calls.insert(chr_sv_calls.end(), std::make_move_iterator(v.begin()), std::make_move_iterator(v.end()));
 }
 
 void SVCaller::hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st)
