@@ -279,6 +279,17 @@ def load_oracle() -> Oracle:
     return Oracle(C.CDLL(ORACLE_SO))
 
 
+def load_ref_O0():
+    """the reference's dbscan.cpp / dbscan1d.cpp / kc.cpp at its SHIPPED flags (Makefile:14 has no -O): oracle/_ref/libcsvref_O0.so"""
+    so = os.path.join(ROOT, "oracle", "_ref", "libcsvref_O0.so")
+    if not os.path.exists(so):
+        if os.path.isdir("/root/reference/src"):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref-O0"])
+        else:
+            return None
+    return Ref(C.CDLL(so))
+
+
 def load_ref():
     if not os.path.exists(REF_SO):
         if os.path.isdir("/root/reference/src"):
