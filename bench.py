@@ -60,6 +60,15 @@ def cpu_share():
     return max(1, n)
 
 
+def cpu_throttle():
+    """(periods throttled, microseconds throttled) of this cgroup so far — a step that exceeds the CPU quota is stalled by the scheduler"""
+    try:
+        kv = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+    except Exception:
+        return None
+
+
 def call_digest(tid, calls):
     """SHA-256 of a run's merged call records (48 B each, contig after contig in the run's order) with their contig ids."""
     h = hashlib.sha256()
@@ -208,6 +217,7 @@ def main():
         ctx.timing_enable(1)                                               # window / Viterbi / DBSCAN1D / final-merge DBSCAN groups on the main context
         ctx.timing_reset()
     barrier()
+    thr0 = cpu_throttle()
     t0 = time.perf_counter()
     acc = None
     for _ in range(args.steps):
@@ -216,6 +226,7 @@ def main():
         acc = vals if acc is None else [a + b for a, b in zip(acc, vals)]
     barrier()
     elapsed = time.perf_counter() - t0
+    thr1 = cpu_throttle()
     timing = {}
     for c in (lane_ctx or []) + [ctx]:
         for k, (ms, n) in c.timing().items():
@@ -305,6 +316,8 @@ def main():
             "stage_counts_rank0": counts,
             "kernel_ms_per_step_rank0": {k: round(v, 4) for k, v in kern.items()},
             "kernel_launches_per_step_rank0": {k: round(v, 1) for k, v in launches.items()},
+            "host_cpu": {"cpus": os.cpu_count(), "share": cpu_share(),
+                         "throttled_in_timed_region": ({"periods": thr1[0] - thr0[0], "ms": round((thr1[1] - thr0[1]) / 1e3, 1)} if thr0 and thr1 else None)},
             "staging_rank0": dict(staging, pcie_inclusive_reads_per_s=reads_mine / (staging["upload_s"] + elapsed / K)),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -63,6 +63,22 @@ int ensure_pinned(csv_ctx *ctx, size_t bytes)
     return CSV_OK;
 }
 
+// Host arrays of the host-pointer entry points travel through the context's page-locked block: the runtime stages a pageable
+// hipMemcpyAsync itself, in chunks and under a lock that the other contexts' launches also take (seen as millisecond gaps in the lanes'
+// big kernels whenever the caller's context copied its observation vectors). in(): bytes copied into the block, the block's address
+// returned for the async copy; out(): a slot of the block the device writes to, copied to the caller's array by finish() after the wait.
+struct PinStage {
+    csv_ctx *ctx;
+    size_t used = 0;
+    struct Out { void *dst; const void *src; size_t bytes; };
+    std::vector<Out> outs;
+    explicit PinStage(csv_ctx *c) : ctx(c) {}
+    static size_t need(size_t bytes) { return (bytes + 255) / 256 * 256; }
+    const void *in(const void *src, size_t bytes) { void *p = (char *)ctx->pinned + used; if (bytes) memcpy(p, src, bytes); used += need(bytes); return p; }
+    void *out(void *dst, size_t bytes) { void *p = (char *)ctx->pinned + used; used += need(bytes); outs.push_back(Out{dst, p, bytes}); return p; }
+    void finish() { for (const Out &o : outs) if (o.bytes) memcpy(o.dst, o.src, o.bytes); outs.clear(); }
+};
+
 static hipEvent_t get_event(csv_ctx *ctx)
 {
     if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
@@ -199,13 +215,18 @@ static int check_reads_dev(csv_ctx *ctx, const csv_reads *r)
 
 // The waits of the per-chromosome pipeline last a fraction of a millisecond: polling for up to a millisecond before blocking
 // saves the tens of microseconds a blocked thread takes to be woken, during which the device has nothing queued.
+static std::chrono::microseconds spin_limit()
+{
+    static const int us = [] { const char *e = getenv("CSV_SPIN_US"); return e && *e ? atoi(e) : 100; }();
+    return std::chrono::microseconds(us);
+}
 static hipError_t wait_stream(hipStream_t s)
 {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) return hipStreamSynchronize(s);
+        if (std::chrono::steady_clock::now() - t0 > spin_limit()) return hipStreamSynchronize(s);
     }
 }
 static hipError_t wait_event(hipEvent_t ev)
@@ -214,7 +235,7 @@ static hipError_t wait_event(hipEvent_t ev)
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) return hipEventSynchronize(ev);
+        if (std::chrono::steady_clock::now() - t0 > spin_limit()) return hipEventSynchronize(ev);
     }
 }
 
@@ -614,22 +635,29 @@ int csvgpu_dbscan_iv_batch(csv_ctx *ctx, const uint32_t *start, const uint32_t *
     uint64_t *doff = (uint64_t *)arena_alloc(ctx->arena, (n_seg + 1) * 8);
     if (!ds || !de || !dl || !doff) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     hipStream_t st = ctx->stream;
-    CSV_HIP(ctx, hipMemcpyAsync(ds, start, n * 4, hipMemcpyHostToDevice, st));
-    CSV_HIP(ctx, hipMemcpyAsync(de, end, n * 4, hipMemcpyHostToDevice, st));
-    CSV_HIP(ctx, hipMemcpyAsync(doff, seg_off, (n_seg + 1) * 8, hipMemcpyHostToDevice, st));
+    if ((rc = ensure_pinned(ctx, 3 * PinStage::need(n * 4) + PinStage::need((n_seg + 1) * 8) + 4096))) return rc;
+    PinStage pin(ctx);
+    CSV_HIP(ctx, hipMemcpyAsync(ds, pin.in(start, n * 4), n * 4, hipMemcpyHostToDevice, st));
+    CSV_HIP(ctx, hipMemcpyAsync(de, pin.in(end, n * 4), n * 4, hipMemcpyHostToDevice, st));
+    CSV_HIP(ctx, hipMemcpyAsync(doff, pin.in(seg_off, (n_seg + 1) * 8), (n_seg + 1) * 8, hipMemcpyHostToDevice, st));
     {
         TimerScope ts(ctx, CSV_K_DBSCAN);
         launch_dbscan_iv_small_batched(st, ds, de, doff, n_seg, eps, min_pts, dl);
     }
     if (max_len > DBSCAN_IV_SMALL_MAX) {                     // the few sets that do not fit a workgroup's LDS: windowed path, one at a time
+        CSV_HIP(ctx, wait_stream(st));                       // (that path reads its sortedness flag back through the same page-locked block)
+        const size_t keep = pin.used;
         for (uint64_t s = 0; s < n_seg; s++) {
             const uint64_t len = seg_off[s + 1] - seg_off[s];
             if (len <= DBSCAN_IV_SMALL_MAX) continue;
             if ((rc = csvgpu_dbscan_iv_dev(ctx, ds + seg_off[s], de + seg_off[s], len, eps, min_pts, dl + seg_off[s]))) return rc;
         }
+        pin.used = keep;
+        if ((rc = ensure_pinned(ctx, keep + PinStage::need(n * 4) + 4096))) return rc;      // (a no-op: sized above)
     }
-    CSV_HIP(ctx, hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, st));
+    CSV_HIP(ctx, hipMemcpyAsync(pin.out(labels, n * 4), dl, n * 4, hipMemcpyDeviceToHost, st));
     CSV_HIP(ctx, wait_stream(st));
+    pin.finish();
     return CSV_OK;
 }
 
@@ -694,11 +722,16 @@ int csvgpu_dbscan_1d(csv_ctx *ctx, const int32_t *pts, const uint64_t *seg_off, 
     int32_t *dp = (int32_t *)arena_alloc(ctx->arena, n * 4), *dl = (int32_t *)arena_alloc(ctx->arena, n * 4);
     uint64_t *doff = (uint64_t *)arena_alloc(ctx->arena, (n_seg + 1) * 8);
     if (!dp || !dl || !doff) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
-    CSV_HIP(ctx, hipMemcpyAsync(dp, pts, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    CSV_HIP(ctx, hipMemcpyAsync(doff, seg_off, (n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ensure_pinned(ctx, 2 * PinStage::need(n * 4) + PinStage::need((n_seg + 1) * 8) + 4096))) return rc;
+    PinStage pin(ctx);
+    CSV_HIP(ctx, hipMemcpyAsync(dp, pin.in(pts, n * 4), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    CSV_HIP(ctx, hipMemcpyAsync(doff, pin.in(seg_off, (n_seg + 1) * 8), (n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (max_len > DBSCAN1D_MAX_SEG) CSV_HIP(ctx, wait_stream(ctx->stream));          // (the large-segment path may use the page-locked block itself)
     if ((rc = csvgpu_dbscan_1d_dev(ctx, dp, doff, n_seg, n, (uint32_t)max_len, eps, min_pts, dl))) return rc;
-    CSV_HIP(ctx, hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (max_len > DBSCAN1D_MAX_SEG && (rc = ensure_pinned(ctx, 2 * PinStage::need(n * 4) + PinStage::need((n_seg + 1) * 8) + 4096))) return rc;
+    CSV_HIP(ctx, hipMemcpyAsync(pin.out(labels, n * 4), dl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     CSV_HIP(ctx, wait_stream(ctx->stream));
+    pin.finish();
     return CSV_OK;
 }
 
@@ -792,16 +825,19 @@ int csvgpu_viterbi(csv_ctx *ctx, const csv_hmm *hmm, const double *o1, const dou
     double *dll = (double *)arena_alloc(a, n_seq * 8);
     if (!d1 || !d2 || !dp || !doff || !dst || !dll) { ctx->err = "arena exhausted"; return CSV_ENOMEM; }
     hipStream_t s = ctx->stream;
+    if ((rc = ensure_pinned(ctx, 3 * PinStage::need(n * 8) + PinStage::need((n_seq + 1) * 8) + PinStage::need(n * 4) + PinStage::need(n_seq * 8) + 4096))) return rc;
+    PinStage pin(ctx);
     if (n) {
-        CSV_HIP(ctx, hipMemcpyAsync(d1, o1, n * 8, hipMemcpyHostToDevice, s));
-        CSV_HIP(ctx, hipMemcpyAsync(d2, o2, n * 8, hipMemcpyHostToDevice, s));
-        CSV_HIP(ctx, hipMemcpyAsync(dp, pfb, n * 8, hipMemcpyHostToDevice, s));
+        CSV_HIP(ctx, hipMemcpyAsync(d1, pin.in(o1, n * 8), n * 8, hipMemcpyHostToDevice, s));
+        CSV_HIP(ctx, hipMemcpyAsync(d2, pin.in(o2, n * 8), n * 8, hipMemcpyHostToDevice, s));
+        CSV_HIP(ctx, hipMemcpyAsync(dp, pin.in(pfb, n * 8), n * 8, hipMemcpyHostToDevice, s));
     }
-    CSV_HIP(ctx, hipMemcpyAsync(doff, seq_off, (n_seq + 1) * 8, hipMemcpyHostToDevice, s));
+    CSV_HIP(ctx, hipMemcpyAsync(doff, pin.in(seq_off, (n_seq + 1) * 8), (n_seq + 1) * 8, hipMemcpyHostToDevice, s));
     if ((rc = csvgpu_viterbi_dev(ctx, hmm, d1, d2, dp, doff, n_seq, n, dst, dll))) return rc;
-    if (n) CSV_HIP(ctx, hipMemcpyAsync(states, dst, n * 4, hipMemcpyDeviceToHost, s));
-    CSV_HIP(ctx, hipMemcpyAsync(loglik, dll, n_seq * 8, hipMemcpyDeviceToHost, s));
+    if (n) CSV_HIP(ctx, hipMemcpyAsync(pin.out(states, n * 4), dst, n * 4, hipMemcpyDeviceToHost, s));
+    CSV_HIP(ctx, hipMemcpyAsync(pin.out(loglik, n_seq * 8), dll, n_seq * 8, hipMemcpyDeviceToHost, s));
     CSV_HIP(ctx, wait_stream(s));
+    pin.finish();
     return CSV_OK;
 }
 
@@ -1304,7 +1340,12 @@ static int split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t 
             if (hipMalloc(&big_supp.p, n_supp * 8) != hipSuccess) { (void)hipGetLastError(); big_supp.p = nullptr; ctx->err = "hipMalloc failed (supplementary hashes)"; return CSV_ENOMEM; }
             d_supp = (uint64_t *)big_supp.p;
         }
-        CSV_HIP(ctx, hipMemcpyAsync(d_supp, supp_hash, n_supp * 8, hipMemcpyHostToDevice, s));
+        // (through the context's page-locked block: a pageable copy is staged by the runtime under a lock the lanes' launches also take)
+        int prc = ensure_pinned(ctx, std::max<size_t>(n_supp * 8, 4096) + 64);
+        if (prc) return prc;
+        memcpy(ctx->pinned, supp_hash, n_supp * 8);
+        CSV_HIP(ctx, hipMemcpyAsync(d_supp, ctx->pinned, n_supp * 8, hipMemcpyHostToDevice, s));
+        CSV_HIP(ctx, wait_stream(s));                    // (the block is reused for the set sizes below)
         if (D == 0) {
             // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
             launch_so_survivors(s, st->tab, n_nodes, st->node_hash, st->node_rec, st->list, d_supp, n_supp, st->d_out, cap, st->d_count);
@@ -1344,8 +1385,10 @@ static int split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t 
         std::vector<csv_split_survivor> &surv = st->surv;
         surv.resize(n_surv);
         if (n_surv) {
-            CSV_HIP(ctx, hipMemcpyAsync(surv.data(), st->d_out, n_surv * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
+            if ((prc = ensure_pinned(ctx, n_surv * sizeof(csv_split_survivor) + 64))) return prc;
+            CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, st->d_out, n_surv * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
             CSV_HIP(ctx, wait_stream(s));
+            memcpy(surv.data(), ctx->pinned, n_surv * sizeof(csv_split_survivor));
         }
         std::sort(surv.begin(), surv.end(), [](const csv_split_survivor &a, const csv_split_survivor &b) { return a.contig != b.contig ? a.contig < b.contig : a.pos < b.pos; });
         for (const csv_split_survivor &v : surv) st->off[v.contig + 1]++;

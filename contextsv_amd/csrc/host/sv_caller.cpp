@@ -440,6 +440,7 @@ struct ShardOrderSource : SplitOrderSource {
     {
         pending.clear();
         if (which.empty() || which.size() > 32) return;                           // (more than one batch: the one-call form below)
+        { const char *e = getenv("CSV_SPLIT_ONE_CALL"); if (e && *e && *e != '0') return; }      // (A/B: no head start)
         std::vector<csv_shard *> sh(which.size());
         for (size_t k = 0; k < which.size(); k++) sh[k] = shard_of[which[k]];
         check(ctx, csvgpu_split_order_begin(ctx, (int)sh.size(), sh.data(), (uint8_t)min_mapq), "split-read order (begin)");

@@ -1,0 +1,11 @@
+#!/bin/bash
+# kernel trace of the last step of a short bench run + the gap report: tools/trace_run.sh OUTDIR [bench args]
+OUT=$(realpath -m "$1"); shift; mkdir -p "$OUT"
+REPO=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-legs --no-cpu-baseline "$@" > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -n 5 "$OUT/trace.log"; exit 1; }
+cd "$REPO"
+python3 tools/trace_step.py "$OUT/trace" > "$OUT/trace_step.txt" 2>&1
+python3 tools/trace_gate.py "$OUT/trace" > "$OUT/trace_gate.txt" 2>&1
+rm -rf "$OUT/trace"
+head -40 "$OUT/trace_step.txt"; head -30 "$OUT/trace_gate.txt"
