@@ -60,6 +60,32 @@ def cpu_share():
     return max(1, n)
 
 
+def pin_to_gpu_numa(device_index):
+    """Keep this process (its host pools, the lanes' threads, the arrays they first touch) on the CPUs of the NUMA node the GPU hangs off:
+    the pool's boxes are two-socket machines whose scheduler otherwise spreads a rank's threads over both sockets (sections of the host
+    passes then run 3-6x slower from one step to the next). CSV_BENCH_NO_PIN=1 leaves the affinity alone. Returns what was done."""
+    if os.environ.get("CSV_BENCH_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if len(cpus) < 4:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "cpus": len(cpus), "gpu": bdf}
+    except Exception as e:          # best effort: an unknown sysfs layout changes nothing
+        return {"error": str(e)[:80]}
+
+
 def cpu_throttle():
     """(periods throttled, microseconds throttled) of this cgroup so far — a step that exceeds the CPU quota is stalled by the scheduler"""
     try:
@@ -135,6 +161,7 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    pinned_to = pin_to_gpu_numa(dev.index)
     coll_dev = torch.device("cpu") if rehearse else dev
     tech = 0 if args.tech == "ont" else 1
     config_id = 3 if tech == 0 else 4                                   # BASELINE.json configs[3] / configs[4]
@@ -147,11 +174,20 @@ def main():
     mine = parallel.assign_shards(lens, world)[rank]
 
     # the caller's own context: split-read ordering (beside the CIGAR pass), copy-number pass, batched DBSCAN1D, final merges
+    # Stream creation order decides who shares a hardware queue (the runtime deals its four queues round-robin): the gate's stream first, so
+    # that the big kernels' queue is shared with the LAST lane at most; CSV_BENCH_STREAM_ORDER = lazy | caller_first for the A/B.
+    n_lanes = max(1, args.lanes)
+    order = os.environ.get("CSV_BENCH_STREAM_ORDER", "gate_first")
+    gate = None
+    if n_lanes > 1 and order == "gate_first":
+        gate = cs.Gate(dev.index)
     ctx = cs.Context(dev.index, background=args.background)
     host.set_context(ctx)
-    n_lanes = max(1, args.lanes)
+    if n_lanes > 1 and order == "caller_first":
+        gate = cs.Gate(dev.index)
     lane_ctx = [cs.Context(dev.index) for _ in range(n_lanes)] if n_lanes > 1 else []
-    gate = cs.Gate() if lane_ctx else None
+    if n_lanes > 1 and gate is None:
+        gate = cs.Gate()
     for c in lane_ctx:
         c.set_gate(gate)
 
@@ -316,7 +352,7 @@ def main():
             "stage_counts_rank0": counts,
             "kernel_ms_per_step_rank0": {k: round(v, 4) for k, v in kern.items()},
             "kernel_launches_per_step_rank0": {k: round(v, 1) for k, v in launches.items()},
-            "host_cpu": {"cpus": os.cpu_count(), "share": cpu_share(),
+            "host_cpu": {"cpus": os.cpu_count(), "share": cpu_share(), "pinned_to": pinned_to,
                          "throttled_in_timed_region": ({"periods": thr1[0] - thr0[0], "ms": round((thr1[1] - thr0[1]) / 1e3, 1)} if thr0 and thr1 else None)},
             "staging_rank0": dict(staging, pcie_inclusive_reads_per_s=reads_mine / (staging["upload_s"] + elapsed / K)),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

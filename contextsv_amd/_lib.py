@@ -79,6 +79,7 @@ ABI = {
     "csvgpu_chr_job_end": (C.c_int, [_P, _P, C.POINTER(csv_chr_result)]),
     "csvgpu_chr_job_abort": (C.c_int, [_P, _P]),
     "csvgpu_gate_create": (_P, []),
+    "csvgpu_gate_open": (C.c_int, [_P, C.c_int]),
     "csvgpu_gate_destroy": (None, [_P]),
     "csvgpu_set_gate": (C.c_int, [_P, _P]),
     "csvgpu_host_alloc": (_P, [_P, C.c_size_t]),

@@ -64,11 +64,16 @@ class Reads:
 class Gate:
     """csv_gate: several Contexts on one GPU queue their scan + depth pairs back to back on the gate's one stream (csvgpu_gate_*)."""
 
-    def __init__(self):
+    def __init__(self, device: int | None = None):
+        """device given: the gate's stream is created now (csvgpu_gate_open) — do that BEFORE creating the lanes' Contexts, see csvgpu.h"""
         self.lib = _lib.load()
         self.h = self.lib.csvgpu_gate_create()
         if not self.h:
             raise CsvError(_lib.CSV_ENOMEM, "csvgpu_gate_create failed")
+        if device is not None:
+            rc = self.lib.csvgpu_gate_open(self.h, device)
+            if rc:
+                raise CsvError(rc, "csvgpu_gate_open failed")
 
     def close(self):
         if getattr(self, "h", None):

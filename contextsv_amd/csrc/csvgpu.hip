@@ -1511,6 +1511,19 @@ int csvgpu_download(csv_ctx *ctx, void *host_dst, const void *dev_src, size_t by
 
 csv_gate *csvgpu_gate_create(void) { return new (std::nothrow) csv_gate(); }
 
+// Creates the gate's stream now instead of at the first job. The runtime deals its hardware queues (four by default) to streams in
+// creation order, and a stream that waits for an event holds up every other stream of its hardware queue: a gate opened BEFORE the lanes'
+// contexts are created shares its queue with none of the first lanes' streams.
+int csvgpu_gate_open(csv_gate *gate, int device_ordinal)
+{
+    if (!gate) return CSV_EINVAL;
+    if (gate->stream) return gate->device == device_ordinal ? CSV_OK : CSV_EINVAL;
+    if (hipSetDevice(device_ordinal) != hipSuccess) { (void)hipGetLastError(); return CSV_ENODEV; }
+    if (hipStreamCreateWithFlags(&gate->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); gate->stream = nullptr; return CSV_EHIP; }
+    gate->device = device_ordinal;
+    return CSV_OK;
+}
+
 void csvgpu_gate_destroy(csv_gate *gate)
 {
     if (!gate) return;
@@ -1562,7 +1575,8 @@ void csvgpu_host_free(csv_ctx *ctx, void *p)
 struct csv_job {
     csv_shard *sh = nullptr;
     uint32_t min_oplen = 50; uint8_t min_mapq = 20; double min_pts_pct = 0.1;
-    hipEvent_t ev_zero = nullptr, ev_scan = nullptr, ev_depth = nullptr, ev_mid = nullptr, ev_done = nullptr;
+    hipEvent_t ev_zero = nullptr, ev_scan = nullptr, ev_depth = nullptr, ev_mid = nullptr, ev_done = nullptr, t0 = nullptr;
+    bool on_gate = false;                // the pair runs on a gate's stream: this context's stream meets it only in job_cluster (ev_depth)
     char *pin = nullptr;                 // 512 B page-locked: [0,256) counters behind the scan, [256,512) counters at the end
     bool depth_queued = false, clustered = false, copied = false;
     uint64_t n = 0, n_del = 0, capacity = 0;
@@ -1628,6 +1642,7 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
     // timed with the two events the job records there anyway plus one in front (scan = ev_scan - t0, depth = ev_depth - ev_scan).
     // (at level 2 only every fourth pair: the extra event in front of the scan is a barrier packet on the stream all lanes share, 2.5 % of
     // the throughput when every pair has one; the averages are over the timed pairs)
+    if (job->t0) { ctx->event_pool.push_back(job->t0); job->t0 = nullptr; }          // (a re-run after the signature buffer grew)
     const bool pair_timers = big != s && ctx->timing != 0 && (ctx->timing == 1 || ctx->timing == 3 || (ctx->timer_tick++ & 3u) == 0);
     hipEvent_t t0 = nullptr;
     if (pair_timers) {
@@ -1647,37 +1662,33 @@ static int job_queue_front(csv_ctx *ctx, csv_job *job)
     if (sh->unsorted >= 0) {
         // The depth pass does not depend on the signature count, so it is queued BEFORE the host waits for the counters: the
         // device works through it while the host wakes up, sizes the ordering and clustering launches and queues them.
-        // The counters leave on a stream that is idle at this point: the context's own when the pair runs on the gate's, else a side stream.
-        hipStream_t cs = s;
-        if (big == s) {
-            if (!ctx->side) CSV_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-            cs = ctx->side;
-        }
-        CSV_HIP(ctx, hipEventRecord(job->ev_scan, big));
-        CSV_HIP(ctx, hipStreamWaitEvent(cs, job->ev_scan, 0));
-        CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, cs));
-        CSV_HIP(ctx, hipEventRecord(job->ev_mid, cs));
-        if (big != s) {                       // (timed through the pair's events, or not at all)
+        job->on_gate = big != s;
+        if (job->on_gate) {
+            // On a gate nothing of this job touches the context's own stream until job_cluster: a caller that queues several jobs ahead must
+            // not find one job's clustering kernels behind a wait for a LATER job's scan. The counters leave from the gate's stream itself,
+            // between the two big kernels (256 bytes to page-locked memory), ev_scan tells the host they have landed, and job_cluster makes
+            // the context's stream wait for ev_depth before min_pts. (A relay through a side stream per context was tried: three more
+            // streams whose only work is to wait share the four hardware queues with everything else and stalled the caller's context.)
+            CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, big));
+            CSV_HIP(ctx, hipEventRecord(job->ev_scan, big));
             launch_depth_tiles(big, sh->d, nullptr, sh->ref_end, sh->ckpt, sh->depth_len, sh->depth, cnt, sh->tile_range, sh->cigar_pad, sh->depth_items, sh->form);
+            CSV_HIP(ctx, hipEventRecord(job->ev_depth, big));
+            turn.unlock();
+            job->t0 = pair_timers ? t0 : nullptr;            // (handed to the timers with ev_scan / ev_depth when the job ends)
         } else {
+            // The counters leave on a side stream beside the depth pass.
+            if (!ctx->side) CSV_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            hipStream_t cs = ctx->side;
+            CSV_HIP(ctx, hipEventRecord(job->ev_scan, big));
+            CSV_HIP(ctx, hipStreamWaitEvent(cs, job->ev_scan, 0));
+            CSV_HIP(ctx, hipMemcpyAsync(job->pin, cnt, sizeof(ScanCounters), hipMemcpyDeviceToHost, cs));
+            CSV_HIP(ctx, hipEventRecord(job->ev_mid, cs));
             ctx->work.used = 0;
             if ((rc = depth_chain(ctx, ctx->work, sh->d, sh->ref_end, sh->ckpt, sh->unsorted != 0, sh->depth_len, sh->depth, cnt,
                                   sorted ? sh->tile_range : nullptr, sh->cigar_pad, sh->depth_items, sh->form))) return rc;
+            launch_min_pts(s, cnt, job->min_pts_pct);
         }
         job->depth_queued = true;
-        if (big != s) {
-            hipEvent_t depth_done = job->ev_depth;
-            CSV_HIP(ctx, hipEventRecord(depth_done, big));
-            turn.unlock();
-            if (pair_timers && t0) {                 // the timers now own the three events (folded when the times are read)
-                Timer a; a.id = CSV_K_CIGAR_SCAN; a.a = t0; a.b = job->ev_scan; a.s = big;
-                Timer b; b.id = CSV_K_DEPTH; b.a = job->ev_scan; b.b = job->ev_depth; b.s = big; b.own_a = false;
-                ctx->timers.push_back(a); ctx->timers.push_back(b);
-                job->ev_scan = nullptr; job->ev_depth = nullptr;
-            }
-            CSV_HIP(ctx, hipStreamWaitEvent(s, depth_done, 0));                // min_pts and the clustering read what the depth pass leaves
-        }
-        launch_min_pts(s, cnt, job->min_pts_pct);
     }
     return CSV_OK;
 }
@@ -1686,6 +1697,15 @@ static void job_free(csv_ctx *ctx, csv_job *job)
 {
     if (!job) return;
     job_pin_release(ctx, job->pin);
+    if (job->t0 && job->ev_scan && job->ev_depth && job->on_gate && ctx->gate && ctx->gate->stream) {
+        // a timed pair on the gate's stream: scan = ev_scan - t0 (the 256-byte counters copy included), depth = ev_depth - ev_scan; the
+        // timers own the three events from here (folded when the times are read)
+        Timer a; a.id = CSV_K_CIGAR_SCAN; a.a = job->t0; a.b = job->ev_scan; a.s = ctx->gate->stream;
+        Timer b; b.id = CSV_K_DEPTH; b.a = job->ev_scan; b.b = job->ev_depth; b.s = ctx->gate->stream; b.own_a = false;
+        ctx->timers.push_back(a); ctx->timers.push_back(b);
+        job->t0 = nullptr; job->ev_scan = nullptr; job->ev_depth = nullptr;
+    }
+    if (job->t0) ctx->event_pool.push_back(job->t0);
     if (job->ev_zero) ctx->event_pool.push_back(job->ev_zero);
     if (job->ev_scan) ctx->event_pool.push_back(job->ev_scan);
     if (job->ev_depth) ctx->event_pool.push_back(job->ev_depth);
@@ -1722,7 +1742,7 @@ int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host
     int rc;
     for (int attempt = 0;; attempt++) {
         if (job->depth_queued) {
-            CSV_HIP(ctx, wait_event(job->ev_mid));
+            CSV_HIP(ctx, wait_event(job->on_gate ? job->ev_scan : job->ev_mid));
             memcpy(&h, job->pin, sizeof(ScanCounters));
         } else {
             if ((rc = read_counters(ctx, cnt, h))) return rc;             // first scan of wrapped arrays: wait, then decide
@@ -1774,6 +1794,11 @@ int csvgpu_chr_job_cluster(csv_ctx *ctx, csv_job *job, double eps, csv_sig *host
     // ordering: DEL calls then INS calls, each in chr_sv_calls order
     order_signatures(ctx, sh->sig_raw, n, sh->depth_len, h.max_start, max_bucket, cnt, true, w, sig_sorted, st, en);
 
+    // min_pts (and with it the clustering) reads what the depth pass leaves; the ordering above did not have to wait for it
+    if (job->depth_queued && job->on_gate) {
+        CSV_HIP(ctx, hipStreamWaitEvent(s, job->ev_depth, 0));
+        launch_min_pts(s, cnt, job->min_pts_pct);
+    }
     // per-type interval DBSCAN (mergeSVs walks DEL ... INS, sv_object.cpp:62-68)
     {
         TimerScope ts(ctx, CSV_K_DBSCAN);
@@ -1821,6 +1846,7 @@ int csvgpu_chr_job_abort(csv_ctx *ctx, csv_job *job)
     // whatever the job queued reads the shard's buffers: let it drain before the caller reuses or frees them
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->gate && ctx->gate->stream) (void)hipStreamSynchronize(ctx->gate->stream);
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     job_free(ctx, job);                                  // ctx->err keeps the failure that led here
     return CSV_OK;
 }

@@ -1,5 +1,7 @@
 #include "sv_caller.h"
 
+#include <deque>
+
 #include <algorithm>
 #include <cstdio>
 #include <chrono>
@@ -143,7 +145,7 @@ void SVCaller::runDeviceChain(const std::string &chr, csv_shard *shard, double e
 // Every CIGAR call has hmm_likelihood == 0, so only the length-ranked branch of the representative choice
 // can run (sv_object.cpp:187-244 of the reference); it is evaluated on the 16-byte signatures and an SVCall
 // (with its strings) is materialised for the chosen member only.
-void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t n_del, uint64_t n_ins, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls)
+void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t n_del, uint64_t n_ins, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, bool share_pool)
 {
     const uint64_t n_sig = n_del + n_ins;
     chr_sv_calls.clear();
@@ -157,7 +159,9 @@ void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t 
         if (type_n[t] < 2) for (uint64_t i = 0; i < type_n[t]; i++) dst.push_back(toSVCall(sig[base + i], seq));
         else mergeSignaturesWithLabels(sig + base, labels + base, type_n[t], seq, dst);
     };
-    if (n_sig < 40000) {
+    // (share_pool = false: a pass over many contigs — the other lanes' merges hide this one, and the host pool belongs to the split-read and
+    // copy-number sections running beside the pass: a merge that took it made those run inline, 1 ms sections became 6 ms ones)
+    if (n_sig < 40000 || !share_pool) {
         one_type(0, chr_sv_calls);
         one_type(1, chr_sv_calls);
         return;
@@ -238,11 +242,11 @@ void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t 
         for (auto &v : W[t].part) chr_sv_calls.insert(chr_sv_calls.end(), std::make_move_iterator(v.begin()), std::make_move_iterator(v.end()));
 }
 
-void SVCaller::hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st)
+void SVCaller::hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st, bool share_pool)
 {
     const double t1 = now_ms();
     printMessage(chr + ": Merging CIGAR...");
-    mergeOrdered(in.sig, in.lab, in.n_del, in.n_ins, seq, chr_sv_calls);
+    mergeOrdered(in.sig, in.lab, in.n_del, in.n_ins, seq, chr_sv_calls, share_pool);
     st.ms_host_merge = now_ms() - t1;
     printMessage(chr + ": Found " + std::to_string(getSVCount(chr_sv_calls)) + " SV candidates in the CIGAR string");
 }
@@ -285,7 +289,7 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
             try {
                 for (size_t i = w; i < n; i += kMergers) {
                     { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return ready[i] || failed; }); if (failed) return; }
-                    hostMerge("shard" + std::to_string(i), slot[i % kSlots], seqs.empty() ? nullptr : seqs[i], calls[i], stats[i]);
+                    hostMerge("shard" + std::to_string(i), slot[i % kSlots], seqs.empty() ? nullptr : seqs[i], calls[i], stats[i], n <= 2);
                     { std::lock_guard<std::mutex> l(mu); merged[i] = 1; }
                     cv.notify_all();
                     if (on_merged) on_merged(i);
@@ -303,12 +307,28 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
         cv.notify_all();
         for (auto &t : workers) pool.wait(t);
     };
-    csv_job *ahead = nullptr;                             // the job whose scan + depth pass is already queued
+    // The scan + depth pair of the next shard (CSV_JOBS_AHEAD of them: 1) is queued ahead of the shard whose results are being fetched. More
+    // than one ahead was measured and is no better (25.7 / 26.7 ms per genome step with one, 26.4 / 26.9 with three): the gaps between the
+    // big kernels were not a starved gate but a lane's stream sharing the gate's hardware queue — see csvgpu_gate_open.
+    static const size_t kAhead = [] { const char *e = getenv("CSV_JOBS_AHEAD"); const int v = e && *e ? atoi(e) : 1; return (size_t)std::min(std::max(v, 1), 8); }();
+    std::deque<csv_job *> ahead;                          // jobs whose scan + depth pass is already queued, oldest first
+    size_t next_begin = 0;
+    auto begin_one = [&] {
+        csv_job *j = csvgpu_chr_job_begin(ctx, shards[next_begin], (uint32_t)min_oplen, (uint8_t)min_mapq, pct);
+        if (!j) throw std::runtime_error(std::string("processChromosome: ") + csvgpu_last_error(ctx));
+        ahead.push_back(j);
+        next_begin++;
+    };
+    auto abort_all = [&] { for (csv_job *j : ahead) csvgpu_chr_job_abort(ctx, j); ahead.clear(); };
+    // (a job works in its shard's own buffers: a shard that is listed again — the benchmark's repeated passes over one contig — is only
+    // begun again once the job before it on that shard has queued its clustering)
+    std::vector<csv_shard *> open_shards;                 // shards of the jobs in `ahead`, same order
+    auto shard_free = [&](csv_shard *sh) { return std::find(open_shards.begin(), open_shards.end(), sh) == open_shards.end(); };
+    auto top_up = [&] {
+        while (next_begin < n && ahead.size() < kAhead && shard_free(shards[next_begin])) { open_shards.push_back(shards[next_begin]); begin_one(); }
+    };
     try {
-        if (n) {
-            ahead = csvgpu_chr_job_begin(ctx, shards[0], (uint32_t)min_oplen, (uint8_t)min_mapq, pct);
-            if (!ahead) throw std::runtime_error(std::string("processChromosome: ") + csvgpu_last_error(ctx));
-        }
+        top_up();
         for (size_t i = 0; i < n; i++) {
             // slot i % kSlots is free once shard i - kSlots has been merged
             if (i >= kSlots) {
@@ -320,20 +340,14 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
             DeviceOut &out = slot[i % kSlots];
             ChrStats &st = stats[i];
             if (!out.cap) out.reserve(ctx, result_capacity_hint(ctx));
-            csv_job *job = ahead;
-            ahead = nullptr;
+            if (ahead.empty()) top_up();                   // (a repeated shard: its next pass could not be queued ahead)
+            csv_job *job = ahead.front();
+            ahead.pop_front();
             int rc = csvgpu_chr_job_cluster(ctx, job, eps, out.sig, out.lab, out.cap);
             if (rc) { csvgpu_chr_job_abort(ctx, job); check(ctx, rc, "processChromosome"); }      // abort keeps the failure's own message
-            // the next shard's scan + depth pass go into the queue now, behind this shard's clustering and copies: the device
-            // does not wait for the host's turn-around (result wait, hand-over to a merge thread, next call)
-            if (i + 1 < n) {
-                ahead = csvgpu_chr_job_begin(ctx, shards[i + 1], (uint32_t)min_oplen, (uint8_t)min_mapq, pct);
-                if (!ahead) {
-                    const std::string why = csvgpu_last_error(ctx);
-                    csvgpu_chr_job_abort(ctx, job);
-                    throw std::runtime_error("processChromosome: " + why);
-                }
-            }
+            open_shards.erase(open_shards.begin());       // this shard's clustering is queued: a later pass over it may follow on the stream
+            // more scan + depth passes go into the queue now, behind this shard's clustering and copies
+            try { top_up(); } catch (...) { csvgpu_chr_job_abort(ctx, job); throw; }
             csv_chr_result res;
             rc = csvgpu_chr_job_end(ctx, job, &res);
             if (rc == CSV_ECAPACITY) {                     // first contig of this size: grow the buffers, fetch what the device still holds
@@ -349,9 +363,9 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
             { std::lock_guard<std::mutex> l(mu); ready[i] = 1; }
             cv.notify_all();
         }
-        if (ahead) { csvgpu_chr_job_abort(ctx, ahead); ahead = nullptr; }      // only after a merge-thread failure cut the loop short
+        abort_all();                                      // (only after a merge-thread failure cut the loop short)
     } catch (...) {
-        if (ahead) csvgpu_chr_job_abort(ctx, ahead);
+        abort_all();
         stop_workers();
         throw;
     }

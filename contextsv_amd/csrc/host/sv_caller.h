@@ -177,7 +177,7 @@ public:
     static SVCall toSVCall(const csv_sig &s, const SeqStore *seq);
     static void mergeSignaturesWithLabels(const csv_sig *sig, const int32_t *labels, uint64_t n, const SeqStore *seq, std::vector<SVCall> &merged);
     // The host half of processChromosome on its own: ordered signatures (DEL block then INS block) + their labels -> merged calls.
-    static void mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t n_del, uint64_t n_ins, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls);
+    static void mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t n_del, uint64_t n_ins, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, bool share_pool = true);
 
 private:
     csv_ctx *ctx;
@@ -202,5 +202,5 @@ private:
         void reserve(csv_ctx *c, uint64_t n);
     };
     void runDeviceChain(const std::string &chr, csv_shard *shard, double eps, double pct, DeviceOut &out, ChrStats &st);
-    static void hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st);
+    static void hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st, bool share_pool = true);
 };

@@ -279,6 +279,9 @@ int csvgpu_chr_job_abort(csv_ctx *ctx, csv_job *job);
  * detach with gate == NULL. Jobs on shards that are not coordinate-sorted ignore the gate. */
 typedef struct csv_gate csv_gate;
 csv_gate *csvgpu_gate_create(void);
+/* Creates the gate's stream now rather than at the first job. Streams get the runtime's hardware queues in creation order and a waiting
+ * stream holds up the others of its queue: open the gate before creating the lanes' contexts. Optional. */
+int csvgpu_gate_open(csv_gate *gate, int device_ordinal);
 void csvgpu_gate_destroy(csv_gate *gate);                 /* after every attached context is destroyed or detached */
 int csvgpu_set_gate(csv_ctx *ctx, csv_gate *gate);
 
