@@ -518,8 +518,8 @@ def leg_chr22(cs, host, dev, args, tech, config_id, gen_threads):
     three copies in three lanes, 200 pipelined passes."""
     syn = host.SynthShard(0x5EED0000 + 1000 * 1 + 22, GRCH38[21] if args.scale == 1.0 else max(200_000, int(GRCH38[21] * args.scale)), args.depth, tech, gen_threads)
     reads, depth_len = syn.reads, syn.depth_len
+    gate = cs.Gate(dev.index)                                  # (before the lanes' contexts: csvgpu_gate_open)
     lanes = [cs.Context(dev.index) for _ in range(3)]
-    gate = cs.Gate()
     shards = []
     try:
         for c in lanes:

@@ -9,8 +9,8 @@ from hmm_params import WGS_HMM
 ap = argparse.ArgumentParser(); ap.add_argument("--lanes", type=int, default=3); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--len", type=int, default=248956422)
 a = ap.parse_args()
 ctx = cs.Context(0); host.set_context(ctx)
+gate = cs.Gate(0) if a.lanes > 1 else None
 lanes = [cs.Context(0) for _ in range(a.lanes)] if a.lanes > 1 else []
-gate = cs.Gate() if lanes else None
 for c in lanes: c.set_gate(gate)
 hmm = cs.make_hmm(**WGS_HMM)
 g = host.Genome()
