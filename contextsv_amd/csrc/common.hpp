@@ -161,7 +161,7 @@ struct ScanExtras {
     int       type_pos = -1, bucket_shift = 0;
 };
 // Forms of the scan (and of the depth pass's walk): a wave per read (long reads), or groups of 16 / 8 lanes per read (short reads)
-enum { SCAN_FORM_WAVE = 0, SCAN_FORM_ROWS16 = 1, SCAN_FORM_ROWS8 = 2 };
+enum { SCAN_FORM_WAVE = 0, SCAN_FORM_ROWS16 = 1, SCAN_FORM_ROWS8 = 2, SCAN_FORM_LANES = 3 };      // (LANES: the scan walks a read per lane; the depth walk takes groups of 16)
 int scan_form_for(uint64_t n_reads, uint64_t n_cigar);          // by mean CIGAR words per read
 void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t depth_len, uint32_t min_oplen,
                        uint32_t min_mapq, int emit, csv_sig *sig_out, uint64_t sig_cap,

@@ -692,7 +692,7 @@ void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, 
 #define CSV_TILE_LAUNCH(PAD, GL)                                                                                                                 \
     hipLaunchKernelGGL((depth_tile_kernel<PAD, GL>), dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag, d.cigar_off, d.cigar, \
                        vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt, it, n_it)
-    if (form == SCAN_FORM_ROWS16) { if (padded) CSV_TILE_LAUNCH(true, 16); else CSV_TILE_LAUNCH(false, 16); }
+    if (form == SCAN_FORM_ROWS16 || form == SCAN_FORM_LANES) { if (padded) CSV_TILE_LAUNCH(true, 16); else CSV_TILE_LAUNCH(false, 16); }
     else if (form == SCAN_FORM_ROWS8) { if (padded) CSV_TILE_LAUNCH(true, 8); else CSV_TILE_LAUNCH(false, 8); }
     else { if (padded) CSV_TILE_LAUNCH(true, WAVE); else CSV_TILE_LAUNCH(false, WAVE); }
 #undef CSV_TILE_LAUNCH

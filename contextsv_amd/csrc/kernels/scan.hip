@@ -20,6 +20,8 @@
 //
 // HBM traffic per read: 4*n_cigar + 23 B in (pos 4, flag 2, mapq 1, cigar_off 2x8 shared) and
 // 12 B out (ref_end, q_start, q_end) + 16 B per signature.
+#include <type_traits>
+
 #include "../common.hpp"
 #include "../devutil.hpp"
 
@@ -712,6 +714,240 @@ __global__ __launch_bounds__(RS_THREADS, rs_occ(GL)) void cigar_scan_rows_kernel
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------- lane-per-read form
+// The group form above still spends ~60 vector instructions per 40-op read on the machinery of sharing a read between lanes (masks for the
+// neighbours' words, two group scans, broadcasts, a window's bookkeeping): for short reads the cheapest walk is the reference's own — one
+// LANE walks one read op by op (sv_caller.cpp:563-656 is that loop), 64 reads per wave at a time. What makes it work on this machine: the
+// 64 reads' words are one contiguous stretch of the array (~10 KiB), staged into the wave's LDS slice with coalesced 16-byte loads, and
+// every lane then reads ITS words from LDS (the strided global loads a lane-per-read walk would issue thrash the L1). Per op: one LDS
+// word, the two length masks, a compare against min_oplen — ~16 instructions for 64 reads at once; signatures, query_start, checkpoints
+// are lane-local events. A batch takes as many consecutive reads as fit the stage; a read longer than the stage (never in a HiFi shard,
+// possible in any input) is walked straight from global memory by its lane.
+constexpr int LN_THREADS = 256;
+constexpr int LN_WAVES = LN_THREADS / WAVE;
+constexpr uint32_t LN_STAGE = 3072;          // words per wave (12 KiB): 64 HiFi reads are ~2 400 words
+
+template <bool PADDED>
+__global__ __launch_bounds__(LN_THREADS, 2) void cigar_scan_lanes_kernel(
+    uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
+    const uint8_t *__restrict__ mapq, const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
+    uint32_t depth_len, uint32_t start_limit, uint32_t min_oplen, uint32_t min_mapq, int emit,
+    csv_sig *__restrict__ sig_out, uint64_t sig_cap, int32_t *__restrict__ ref_end, int32_t *__restrict__ q_start,
+    int32_t *__restrict__ q_end, uint32_t *__restrict__ ckpt, ScanCounters *__restrict__ cnt,
+    unsigned long long *__restrict__ tile_range, uint32_t n_tiles, uint32_t *__restrict__ bucket_hist, int hist_type_pos, int hist_shift,
+    const uint64_t *__restrict__ split)
+{
+    __shared__ csv_sig buf[SIG_BUF];
+    __shared__ alignas(16) uint32_t stage[LN_WAVES][LN_STAGE + 8];      // (+ slack: the walk requests four words at a time)
+    __shared__ uint32_t tr_first[TR_SLOTS], tr_last[TR_SLOTS];
+    __shared__ uint32_t buf_n, blk_n_del, blk_overflow, tr_base;
+    __shared__ unsigned long long blk_gbase;
+    __shared__ uint64_t split_s[LN_WAVES + 1];
+
+    const int lane = lane_id();
+    const int wave = (int)uniform32(threadIdx.x >> 6);
+    if (threadIdx.x == 0) { buf_n = 0; blk_n_del = 0; blk_overflow = 0; }
+    if (threadIdx.x < TR_SLOTS) { tr_first[threadIdx.x] = 0; tr_last[threadIdx.x] = 0; }
+    const uint64_t n_waves = (uint64_t)gridDim.x * LN_WAVES;
+    const uint64_t wave_gid = (uint64_t)blockIdx.x * LN_WAVES + wave;
+    const uint64_t share = (n_cigar + n_waves - 1) / n_waves;
+    if (split) {
+        if (threadIdx.x <= LN_WAVES) split_s[threadIdx.x] = split[2 * ((uint64_t)blockIdx.x * LN_WAVES + threadIdx.x)];
+    } else {
+        const uint64_t b = wave_lower_bound(cigar_off, n_reads, wave_gid * share, lane);
+        if (lane == 0) split_s[wave] = b;
+        if (wave == LN_WAVES - 1) {
+            const uint64_t e = (wave_gid + 1 >= n_waves) ? n_reads : wave_lower_bound(cigar_off, n_reads, (wave_gid + 1) * share, lane);
+            if (lane == 0) split_s[LN_WAVES] = e;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t r0 = split_s[0];
+        tr_base = (tile_range && r0 < n_reads) ? (((uint32_t)pos[r0] + 1u) >> DEPTH_TILE_SHIFT) : 0u;
+    }
+    __syncthreads();
+    const uint64_t r_begin = uniform64(split_s[wave]);
+    const uint64_t r_end = uniform64(split_s[wave + 1]);
+    const uint32_t tbase = tr_base;
+    uint32_t *__restrict__ const st = stage[wave];
+    uint32_t my_n_del = 0, my_overflow = 0, my_bucket_max = 0;
+
+    for (uint64_t rb = r_begin; rb < r_end;) {
+        const uint32_t avail = (uint32_t)min((uint64_t)WAVE, r_end - rb);
+        // lane l <-> read rb + l: offsets first, to see how many reads the stage takes
+        uint32_t c0 = 0, nw = 0, p0 = 0, fl = 0, mq = 0, l_uns = 0;
+        const uint64_t rr = rb + lane;
+        if ((uint32_t)lane < avail) {
+            const uint64_t a = cigar_off[rr], b = cigar_off[rr + 1];
+            c0 = (uint32_t)a; nw = (uint32_t)(b - a);
+            const int32_t p = pos[rr];
+            p0 = (uint32_t)p; fl = flag[rr]; mq = mapq[rr];
+            l_uns = (rr > 0 && p < pos[rr - 1]) ? 1u : 0u;
+        }
+        if (__ballot(l_uns != 0) && lane == 0) cnt->unsorted = 1u;
+        const uint32_t base = bcast32(c0, 0) & ~3u;                  // the stage starts on a 16-byte boundary
+        const bool fits = (uint32_t)lane < avail && (c0 + nw) - base <= LN_STAGE;          // (offsets grow with the lane: a prefix of the lanes)
+        const uint64_t fit_mask = __ballot(fits);
+        uint32_t nb = ~fit_mask ? (uint32_t)__builtin_ctzll(~fit_mask) : (uint32_t)WAVE;      // leading run of reads that fit together
+        const bool direct = nb == 0;                                 // the first read alone is larger than the stage: its lane reads global memory
+        if (direct) nb = 1;
+        const bool mine = (uint32_t)lane < nb;
+        if (!direct) {
+            const uint32_t n_stage = bcast32(c0 + nw, nb - 1) - base;
+            if (PADDED) {
+                // LDS-DMA, 1 KiB per instruction, all of them in flight at once (a loop of load -> store pairs waited a round trip per KiB)
+                const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(st));
+                for (uint32_t i = 0; i < n_stage; i += CHUNK_WORDS) glds16(cigar + base + i, (uint32_t)lane * 16u, lds0 + i * 4u);
+                ring_wait_all();
+            } else {
+                for (uint32_t i = (uint32_t)lane * 4; i < n_stage; i += WAVE * 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) st[i + k] = ((uint64_t)base + i + k < n_cigar) ? cigar[base + i + k] : (uint32_t)OP_P;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // ---- every lane walks its read (sv_caller.cpp:563-656, :663-690)
+        const bool emit_ok = emit && mine && !(fl & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL | F_SUPP)) && mq >= min_mapq;
+        const uint32_t n_mine = mine ? nw : 0u;
+        uint32_t ref = 0, q = 0, skipped_sum = 0;
+        int32_t qs = -1;
+        const uint32_t off = c0 - base;
+        uint32_t next_ck = (CKPT_WORDS - (c0 & (CKPT_WORDS - 1))) & (CKPT_WORDS - 1);      // first k > 0 whose word sits on a checkpoint boundary
+        if (next_ck == 0) next_ck = CKPT_WORDS;
+        // (two instances of the loop: with the source chosen inside it the compiler merges the two loads into one FLAT load through a generic
+        // pointer — a memory-latency operation per op even when the word sits in LDS: 2x the whole kernel)
+        auto walk = [&](auto direct_c) {
+        constexpr bool DIRECT = decltype(direct_c)::value;
+        // four words per step: the four LDS reads are issued together and waited for once (a word per step paid the LDS latency per op —
+        // with two waves per SIMD nothing hides it), the words of the NEXT step are requested before this step's are worked on
+        uint32_t wn[4];
+        auto fetch = [&](uint32_t k0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (DIRECT) wn[j] = (k0 + j < n_mine) ? cigar[(uint64_t)c0 + k0 + j] : (uint32_t)OP_P;
+                else wn[j] = st[off + k0 + j];                       // (up to three words past the read's end: inside the stage's slack, never used)
+            }
+        };
+        fetch(0);
+        for (uint32_t k = 0; __ballot(k < n_mine); k += 4) {
+            uint32_t wc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wc[j] = wn[j];
+            if (__ballot(k + 4 < n_mine)) fetch(k + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+            if (k + j < n_mine) {
+                const uint32_t w = wc[j];
+                const uint32_t kk = k + j;
+                const uint32_t len = w >> 4;
+                const uint32_t rl = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), w, 1u);
+                const uint32_t ql = len & (uint32_t)__builtin_amdgcn_sbfe((int)(QRY_OPS | (QRY_OPS << 16)), w, 1u);
+                if (kk == next_ck) { ckpt[(c0 + kk) >> CKPT_SHIFT] = ref; next_ck += CKPT_WORDS; }
+                if (qs < 0 && __builtin_amdgcn_sbfe((int)(QST_OPS | (QST_OPS << 16)), w, 1u)) qs = (int32_t)q;
+                if (len >= min_oplen && emit_ok) {
+                    const uint32_t op = w & 15u;
+                    if (op == OP_I || op == OP_D || op == OP_S) {
+                        const uint32_t rp = p0 + ref;
+                        if (op == OP_S && (uint32_t)(rp + 1u) >= depth_len) skipped_sum += len;      // the `continue` at :602-604: no call, no cursor update
+                        else {
+                            csv_sig sg;
+                            sg.start = rp + 1u;
+                            sg.end = sg.start + len - 1u;
+                            sg.read = (uint32_t)rr;
+                            const uint32_t kind = (op == OP_I) ? CSV_KIND_INS : (op == OP_D ? CSV_KIND_DEL : CSV_KIND_CLIP);
+                            sg.qpos_kind = ((q - skipped_sum) << 2) | kind;
+                            const uint32_t sl = atomicAdd(&buf_n, 1u);
+                            if (sl < SIG_BUF) buf[sl] = sg;
+                            else {
+                                const unsigned long long gi = atomicAdd(&cnt->n_sig, 1ull);
+                                if (gi < sig_cap) sig_out[gi] = sg;
+                                if (bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
+                            }
+                            my_n_del += (kind == CSV_KIND_DEL);
+                            my_overflow |= (sg.start >= start_limit);
+                        }
+                    }
+                }
+                ref += rl; q += ql;
+            }
+            }
+        }
+        };
+#ifndef LN_KO_WALK
+        if (direct) walk(std::true_type{}); else walk(std::false_type{});
+#endif
+        // ---- the batch's outputs, lane-parallel
+        uint32_t t0 = 1, t1 = 0;
+        if (mine) {
+            uint32_t rlen = (fl & F_UNMAP) ? 0u : ref;               // htslib bam_endpos: pos + rlen, rlen == 0 (or unmapped) -> 1
+            if (rlen == 0) rlen = 1;
+            ref_end[rr] = (int32_t)(p0 + rlen);
+            q_start[rr] = qs < 0 ? 0 : qs;
+            q_end[rr] = (int32_t)q;
+            if (tile_range && ref != 0 && !(fl & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP))) {
+                const uint32_t first = p0 + 1u, lastp = first + ref - 1u;
+                if ((first >> DEPTH_TILE_SHIFT) < n_tiles && lastp >= first) { t0 = first >> DEPTH_TILE_SHIFT; t1 = min(lastp >> DEPTH_TILE_SHIFT, n_tiles - 1u); }
+            }
+        }
+        auto mark = [&](uint32_t tt, uint32_t rd) {
+            const uint32_t sl = tt - tbase;
+            if (sl < TR_SLOTS) {
+                atomicMax(&tr_first[sl], ~rd);
+                atomicMax(&tr_last[sl], rd + 1u);
+            } else {
+                atomicMax(&tile_range[2 * (uint64_t)tt], ~(unsigned long long)rd);
+                atomicMax(&tile_range[2 * (uint64_t)tt + 1], (unsigned long long)rd + 1ull);
+            }
+        };
+        const bool wide = t1 >= t0 && t1 - t0 >= 8u;
+        if (t1 >= t0 && !wide) for (uint32_t tt = t0; tt <= t1; tt++) mark(tt, (uint32_t)rr);
+        for (uint64_t mw = __ballot(wide); mw; mw &= mw - 1) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(mw);
+            const uint32_t a0 = bcast32(t0, src), a1 = bcast32(t1, src), rd = (uint32_t)rb + src;
+            for (uint32_t tt = a0 + (uint32_t)lane; tt <= a1; tt += WAVE) mark(tt, rd);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // the stage is refilled by the next batch
+        rb += nb;
+    }
+
+    // workgroup epilogue (as cigar_scan_rows_kernel's)
+    my_n_del = wave_sum(my_n_del);
+    const bool wave_overflow = __ballot(my_overflow != 0) != 0;
+    if (lane == 0) {
+        if (my_n_del) atomicAdd(&blk_n_del, my_n_del);
+        if (wave_overflow) atomicOr(&blk_overflow, 1u);
+    }
+    __syncthreads();
+    if (tile_range && threadIdx.x < TR_SLOTS && tr_last[threadIdx.x]) {
+        const uint64_t tt = (uint64_t)tbase + threadIdx.x;
+        atomicMax(&tile_range[2 * tt], ~(unsigned long long)(uint32_t)~tr_first[threadIdx.x]);
+        atomicMax(&tile_range[2 * tt + 1], (unsigned long long)tr_last[threadIdx.x]);
+    }
+    if (!emit) return;
+    const uint32_t nbuf = min(buf_n, SIG_BUF);
+    if (threadIdx.x == 0) {
+        blk_gbase = nbuf ? atomicAdd(&cnt->n_sig, (unsigned long long)nbuf) : 0ull;
+        if (blk_n_del) atomicAdd(&cnt->n_del, (unsigned long long)blk_n_del);
+        if (blk_overflow) cnt->max_start = 0xffffffffu;
+    }
+    __syncthreads();
+    const unsigned long long gb = blk_gbase;
+    for (uint32_t i = threadIdx.x; i < nbuf; i += LN_THREADS) {
+        const csv_sig sg = buf[i];
+        if (gb + i < sig_cap) sig_out[gb + i] = sg;
+        if (bucket_hist) my_bucket_max = max(my_bucket_max, atomicAdd(&bucket_hist[bk_bucket(sg, hist_type_pos, hist_shift)], 1u) + 1u);
+    }
+    if (bucket_hist) {
+        my_bucket_max = wave_max(my_bucket_max);
+        if (lane == 0 && my_bucket_max > BK_LOCAL_MAX) atomicMax(&cnt->max_len, my_bucket_max);
+    }
+}
+
 // Signature starts are < depth_len for coordinate-sorted input (start = pos + 1 <= contig length); the ordering pass sizes its
 // radix keys from this bound, and the scan raises ScanCounters::max_start to 0xffffffff if a start ever exceeds it.
 uint32_t scan_start_limit(uint32_t depth_len)
@@ -725,13 +961,14 @@ uint32_t scan_start_limit(uint32_t depth_len)
 // filled round of workgroups; two rounds measured best (0.177 ms; 0.191 at one round, 0.179 at three to four, 0.192 at six)
 static unsigned scan_grid(int n_cu, uint64_t n_reads, int form)
 {
-    static int blocks_per_cu[3] = {0, 0, 0};
+    static int blocks_per_cu[4] = {0, 0, 0, 0};
     if (blocks_per_cu[form] == 0) {
         int occ = 0;
         hipError_t e;
         if (form == SCAN_FORM_WAVE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_kernel, SCAN_THREADS, 0);
         else if (form == SCAN_FORM_ROWS16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_rows_kernel<16, true>, RS_THREADS, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_rows_kernel<8, true>, RS_THREADS, 0);
+        else if (form == SCAN_FORM_ROWS8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_rows_kernel<8, true>, RS_THREADS, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cigar_scan_lanes_kernel<true>, LN_THREADS, 0);
         if (e != hipSuccess || occ <= 0) { (void)hipGetLastError(); occ = 4; }
         blocks_per_cu[form] = occ;
     }
@@ -740,8 +977,10 @@ static unsigned scan_grid(int n_cu, uint64_t n_reads, int form)
         const uint64_t cap = (uint64_t)n_cu * blocks_per_cu[form] * 2;
         return (unsigned)(want < cap ? want : cap);
     }
-    // short reads: a wave wants a few dozen reads (its groups run through them side by side); one round of workgroups while they all fit, else two
-    const uint64_t want = (n_reads + (uint64_t)RS_WAVES * RS_MIN_READS - 1) / ((uint64_t)RS_WAVES * RS_MIN_READS);
+    // short reads: a wave wants a few dozen reads (its groups run through them side by side; the lane form takes 64 at a time and wants a few
+    // batches per wave); one round of workgroups while they all fit, else two
+    const uint64_t per_wave = form == SCAN_FORM_LANES ? 128 : RS_MIN_READS;
+    const uint64_t want = (n_reads + (uint64_t)RS_WAVES * per_wave - 1) / ((uint64_t)RS_WAVES * per_wave);
     const uint64_t slots = (uint64_t)n_cu * blocks_per_cu[form];
     return (unsigned)(want <= slots ? want : 2 * slots);
 }
@@ -758,13 +997,13 @@ __global__ __launch_bounds__(256) void scan_split_kernel(const uint64_t *__restr
 }
 
 // Which form of the scan (and of the depth pass's walk) suits a shard: reads of a few dozen ops (HiFi) are walked by groups of lanes,
-// several reads per wave; long reads (ONT: ~1 200 ops) by a wave each. CSV_SCAN_FORM = 0 / 1 / 2 overrides (experiments, tests).
+// several reads per wave; long reads (ONT: ~1 200 ops) by a wave each. CSV_SCAN_FORM = 0 / 1 / 2 / 3 overrides (experiments, tests).
 int scan_form_for(uint64_t n_reads, uint64_t n_cigar)
 {
     const char *e = getenv("CSV_SCAN_FORM");
     const int forced = e && *e ? atoi(e) : -1;
     if (n_cigar >= 0xffffffffull) return SCAN_FORM_WAVE;          // the short-read form indexes words in 32 bits
-    if (forced >= 0 && forced <= 2) return forced;
+    if (forced >= 0 && forced <= 3) return forced;
     return (n_reads && n_cigar / n_reads < 192) ? SCAN_FORM_ROWS16 : SCAN_FORM_WAVE;
 }
 
@@ -804,7 +1043,16 @@ void launch_cigar_scan(hipStream_t s, int n_cu, const csv_reads &d, uint32_t dep
                        d.cigar, depth_len, scan_start_limit(depth_len), min_oplen, min_mapq, emit, sig_out, sig_cap, ref_end, q_start, q_end, ckpt, cnt,  \
                        (unsigned long long *)x.tile_range, x.n_tiles, emit ? x.bucket_hist : nullptr, x.type_pos, x.bucket_shift, split)
     if (form == SCAN_FORM_ROWS16) { if (padded) CSV_ROWS_LAUNCH(16, true); else CSV_ROWS_LAUNCH(16, false); }
-    else { if (padded) CSV_ROWS_LAUNCH(8, true); else CSV_ROWS_LAUNCH(8, false); }
+    else if (form == SCAN_FORM_ROWS8) { if (padded) CSV_ROWS_LAUNCH(8, true); else CSV_ROWS_LAUNCH(8, false); }
+    else {
+        static_assert(LN_WAVES == SCAN_WAVES, "one split table layout for every form");
+#define CSV_LANES_LAUNCH(PAD)                                                                                                                        \
+    hipLaunchKernelGGL((cigar_scan_lanes_kernel<PAD>), dim3(grid), dim3(LN_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag, d.mapq, d.cigar_off,   \
+                       d.cigar, depth_len, scan_start_limit(depth_len), min_oplen, min_mapq, emit, sig_out, sig_cap, ref_end, q_start, q_end, ckpt, cnt,  \
+                       (unsigned long long *)x.tile_range, x.n_tiles, emit ? x.bucket_hist : nullptr, x.type_pos, x.bucket_shift, split)
+        if (padded) CSV_LANES_LAUNCH(true); else CSV_LANES_LAUNCH(false);
+#undef CSV_LANES_LAUNCH
+    }
 #undef CSV_ROWS_LAUNCH
 }
 

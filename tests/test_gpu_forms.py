@@ -1,4 +1,4 @@
-"""The three forms of the scan and of the depth walk (a wave per read; groups of 16 or 8 lanes per read: scan.hip, depth.hip) on the same
+"""The forms of the scan and of the depth walk (a wave per read; groups of 16 or 8 lanes per read; a lane per read: scan.hip, depth.hip) on the same
 shards, each against the oracle: signatures, alignment intervals, depth map, sums. The form is normally chosen per shard from the mean
 CIGAR words per read; CSV_SCAN_FORM forces it (read when a shard is created / a host-pointer entry point is called). Both instances of
 every kernel are covered: host-pointer entry points stage an UNPADDED copy (bounds-checked loads), resident shards are padded."""
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 M, I, D, N, S, H, P, EQ, X = range(9)
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["wave", "rows16", "rows8"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["wave", "rows16", "rows8", "lanes"])
 def form(request):
     old = os.environ.get("CSV_SCAN_FORM")
     os.environ["CSV_SCAN_FORM"] = str(request.param)

@@ -3,7 +3,7 @@
 out=${1:-gpurun_out/r03/forms}
 mkdir -p "$(dirname "$out")"
 rc=0
-for f in 0 1 2; do
+for f in 0 1 3; do
   for w in "--contig 22 --tech hifi --depth 60" "--contig 1 --tech hifi --depth 60"; do
     CSV_SCAN_FORM=$f python tools/kernel_probe.py $w 2>> "$out.err" | tee -a "$out.json" | python -c "
 import json,sys
