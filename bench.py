@@ -317,11 +317,12 @@ def main():
         ach = alg_bytes[dominant] / (kern[dominant] * 1e-3) / 1e9 if kern.get(dominant, 0) > 0 else 0.0
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and world == 1 and args.scale == 1.0 and n_contigs == 24 and tech == 0:
+        if os.path.exists(pmc_path) and world == 1 and args.scale == 1.0 and n_contigs == 24 and ((tech == 0 and args.depth == 30.0) or (tech == 1 and args.depth == 60.0)):
             try:
                 pj = json.load(open(pmc_path))
-                traffic = pj.get("wgs", {}).get(dominant)
-                traffic_src = pj.get("wgs", {}).get("source")
+                key = "wgs" if tech == 0 else "hifi_wgs"
+                traffic = pj.get(key, {}).get(dominant)
+                traffic_src = pj.get(key, {}).get("source")
             except Exception:
                 traffic = None
         workload = (f"whole genome: {n_contigs} GRCh38 primary contig lengths" + (f" x {args.scale:g}" if args.scale != 1.0 else "") +
@@ -424,6 +425,15 @@ def main():
         dist.destroy_process_group()
 
 
+def _hifi_traffic():
+    """HBM bytes per 60x HiFi genome step of the two big kernels from the committed PMC passes (profiles/pmc_traffic.json: tools/profile_round.sh ... hifi)"""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("hifi_wgs", {})
+        return {"cigar_scan": pj.get("cigar_scan"), "depth": pj.get("depth"), "source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+    except Exception:
+        return None
+
+
 def leg_hifi_wgs(stage, ctx, lane_ctx, hmm, args, n_contigs, cap):
     """BASELINE configs[4]'s workload on one GPU: the same 24 contig lengths at 60x synthetic PacBio HiFi (1.04e7 reads of ~37 CIGAR ops:
     ten times the reads of the ONT genome in a twentieth of the CIGAR words) through the same step. The scan and the depth walk take their
@@ -468,7 +478,7 @@ def leg_hifi_wgs(stage, ctx, lane_ctx, hmm, args, n_contigs, cap):
                 "cigar_scan_frac": round(b_scan / (kern["cigar_scan"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern.get("cigar_scan") else None,
                 "depth_GBps": round(b_depth / (kern["depth"] * 1e-3) / 1e9, 1) if kern.get("depth") else None,
                 "depth_frac": round(b_depth / (kern["depth"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern.get("depth") else None,
-                "staging": staging,
+                "staging": staging, "traffic_bytes_per_step": _hifi_traffic(),
                 "note": "kernel times are HIP-event times on the gate's stream inside the step (the other lanes' small kernels and the split-read pass's ordering kernels "
                         "share the device); algorithmic bytes as for the headline: scan 4 m + 23 n + 16 n_sig, depth 4 m + 4 (L + 1)"}
     finally:
