@@ -314,7 +314,9 @@ extern "C" void csvgpu_debug_depth_phase(unsigned long long *out, int reset)
 // every chunk load is one unconditional 16-byte load per lane.
 // GL: lanes that walk one item together — 64 (a wave per item, the stream of 1 KiB chunks below: long reads) or 16 / 8 (short reads:
 // a (tile, read) item of a HiFi shard is 40 words, and a whole wave per item left 5 lanes in 6 idle; 64-word windows, see scan.hip).
-template <bool PADDED, int GL>
+// WPL (wave-per-item walk only): CIGAR words per lane and chunk visit — 4 (1 KiB chunks, six in flight) or 8 (2 KiB chunks, three in flight: the
+// per-visit bookkeeping, the wave scan and the span update once per 512 words instead of once per 256).
+template <bool PADDED, int GL, int WPL = 4>
 __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
     uint64_t n_reads, uint64_t n_cigar, const int32_t *__restrict__ pos, const uint16_t *__restrict__ flag,
     const uint64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int vec_ok, int dvec_ok,
@@ -388,20 +390,20 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
             // Short reads: every group of GL lanes takes the items gid, gid + n_groups, ... of the list and walks each in 64-word windows from the
             // item's first valid word rounded down to 16 bytes (an item of a HiFi shard is one window); the next window's words — the next
             // item's, usually — are requested before the current one is decoded. Same arithmetic as the stream below, per group.
-            constexpr int WPL = WAVE / GL;
+            constexpr int GW = WAVE / GL;       // words per lane and window
             constexpr uint32_t NGRP = DEPTH_THREADS / GL;
             const uint32_t sub = threadIdx.x & (uint32_t)(GL - 1), gid = threadIdx.x / (uint32_t)GL;
             const uint32_t upper = (lane & 8) ? 0xffffffffu : 0u;
-            auto loadw = [&](uint32_t g, uint32_t (&ww)[WPL]) {
+            auto loadw = [&](uint32_t g, uint32_t (&ww)[GW]) {
                 if (PADDED) {
 #pragma unroll
-                    for (int q = 0; q < WPL; q += 4) {
+                    for (int q = 0; q < GW; q += 4) {
                         const uint4 x = *reinterpret_cast<const uint4 *>(cigar + g + q);
                         ww[q] = x.x; ww[q + 1] = x.y; ww[q + 2] = x.z; ww[q + 3] = x.w;
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < WPL; k++) ww[k] = ((uint64_t)g + k < n_cigar) ? cigar[g + k] : (uint32_t)OP_P;
+                    for (int k = 0; k < GW; k++) ww[k] = ((uint64_t)g + k < n_cigar) ? cigar[g + k] : (uint32_t)OP_P;
                 }
             };
             uint32_t it = gid;
@@ -409,8 +411,8 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
             uint4 cd = *reinterpret_cast<const uint4 *>(&wl[act ? it : 0u]);       // {b0, nrem, pack, start}
             uint32_t v = 0;
             int32_t base_rel = 0;
-            uint32_t ww[WPL];
-            loadw(act ? (((cd.x << CKPT_SHIFT) + (cd.z & 63u)) & ~3u) + sub * WPL : 0u, ww);
+            uint32_t ww[GW];
+            loadw(act ? (((cd.x << CKPT_SHIFT) + (cd.z & 63u)) & ~3u) + sub * GW : 0u, ww);
             while (__ballot(act)) {
                 const uint32_t fv = (cd.x << CKPT_SHIFT) + (cd.z & 63u);            // first valid word (32-bit word indices: the short-read forms are only chosen below 2^32 words)
                 const uint32_t nval = act ? cd.y - (cd.z & 63u) : 0u;             // valid words from there
@@ -422,14 +424,14 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                 uint4 nd = cd;
                 if (last) nd = *reinterpret_cast<const uint4 *>(&wl[nact ? nit : 0u]);
                 const uint32_t nv = last ? 0u : v + 1u;
-                uint32_t wn[WPL];
-                loadw(nact ? (((nd.x << CKPT_SHIFT) + (nd.z & 63u)) & ~3u) + nv * 64u + sub * WPL : 0u, wn);
+                uint32_t wn[GW];
+                loadw(nact ? (((nd.x << CKPT_SHIFT) + (nd.z & 63u)) & ~3u) + nv * 64u + sub * GW : 0u, wn);
 
                 if (v == 0) base_rel = (int32_t)cd.w;
-                const uint32_t t = a + v * 64u + sub * WPL - fv;
-                uint32_t rl[WPL], gp[WPL], lane_ref = 0;
+                const uint32_t t = a + v * 64u + sub * GW - fv;
+                uint32_t rl[GW], gp[GW], lane_ref = 0;
 #pragma unroll
-                for (int k = 0; k < WPL; k++) {
+                for (int k = 0; k < GW; k++) {
                     if (!((uint32_t)(t + k) < nval)) ww[k] = (uint32_t)OP_P;
                     const uint32_t len = ww[k] >> 4;
                     rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), ww[k], 1u);
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                 {
                     int32_t rel = base_rel + (int32_t)(incl - lane_ref), ca = clamp0_i32(rel, TW);
 #pragma unroll
-                    for (int k = 0; k < WPL; k++) {
+                    for (int k = 0; k < GW; k++) {
                         rel += (int32_t)rl[k];
                         const int32_t cb2 = clamp0_i32(rel, TW);
                         if (gp[k]) {
@@ -458,13 +460,15 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                 base_rel += total;
                 if (last) { v = 0; it = nit; cd = nd; act = nact; } else v = nv;
 #pragma unroll
-                for (int k = 0; k < WPL; k++) ww[k] = wn[k];
+                for (int k = 0; k < GW; k++) ww[k] = wn[k];
             }
         } else if (n_items) {
-            uint32_t w[DEPTH_PF + 1][4];
-            uint32_t m_o0[DEPTH_PF + 1], m_nrem[DEPTH_PF + 1], m_c0rel[DEPTH_PF + 1];
-            int32_t m_start[DEPTH_PF + 1];
-            bool m_valid[DEPTH_PF + 1], m_first[DEPTH_PF + 1];
+            constexpr int NS = WPL == 8 ? 3 : DEPTH_PF + 1;                            // ring slots (chunks in flight)
+            constexpr uint32_t CW = (uint32_t)WPL * WAVE;                            // words per chunk
+            uint32_t w[NS][WPL];
+            uint32_t m_o0[NS], m_nrem[NS], m_c0rel[NS];
+            int32_t m_start[NS];
+            bool m_valid[NS], m_first[NS];
             uint64_t f_chunk0 = 0, f_addr = 0;
             uint32_t f_n = 0, f_c = 0, f_nrem = 0, f_c0rel = 0, f_off = 0;
             int32_t f_start = 0;
@@ -480,53 +484,66 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                         f_nrem = uniform32(d.y);
                         f_start = (int32_t)uniform32(d.w);
                         const uint32_t pk = uniform32(d.z);
-                        f_n = pk >> 6; f_c0rel = pk & 63u; f_c = 0;
+                        f_n = WPL == 4 ? pk >> 6 : (f_nrem + CW - 1) / CW; f_c0rel = pk & 63u; f_c = 0;
                         if (lane == 0) nxt_v = atomicAdd(&next_item, 1u);
                     } else f_done = true;
                 }
                 m_valid[j] = !f_done;
                 if (!f_done) {
-                    m_o0[j] = f_c * (4 * WAVE); m_nrem[j] = f_nrem; m_c0rel[j] = f_c0rel; m_start[j] = f_start; m_first[j] = f_c == 0;
-                    f_off = f_c * (4 * WAVE);
+                    m_o0[j] = f_c * CW; m_nrem[j] = f_nrem; m_c0rel[j] = f_c0rel; m_start[j] = f_start; m_first[j] = f_c == 0;
+                    f_off = f_c * CW;
                     f_addr = f_chunk0 + (uint64_t)f_off;
                     f_c++;
                 }
                 if (PADDED) {
-                    // lanes whose four words all lie behind the item's last word repeat the last lane that has one: no cache line is fetched
+                    // lanes whose words all lie behind the item's last word repeat the last lane that has one: no cache line is fetched
                     // for them, and the load stays unconditional (the consumer masks those words anyway)
-                    const uint32_t lw = min((uint32_t)lane * 4, (f_nrem - 1u - f_off) & ~3u);
-                    const uint4 v = *reinterpret_cast<const uint4 *>(cigar + f_addr + lw);
-                    w[j][0] = v.x; w[j][1] = v.y; w[j][2] = v.z; w[j][3] = v.w;
-                } else if (vec_ok && f_addr + 4 * WAVE <= n_cigar) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(cigar + f_addr + (uint64_t)lane * 4);
-                    w[j][0] = v.x; w[j][1] = v.y; w[j][2] = v.z; w[j][3] = v.w;
-                } else depth_load4(cigar, n_cigar, vec_ok, f_addr + (uint64_t)lane * 4, w[j]);
+                    const uint32_t lw = min((uint32_t)lane * WPL, (f_nrem - 1u - f_off) & ~(uint32_t)(WPL - 1));
+#pragma unroll
+                    for (int q = 0; q < WPL; q += 4) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(cigar + f_addr + lw + q);
+                        w[j][q] = v.x; w[j][q + 1] = v.y; w[j][q + 2] = v.z; w[j][q + 3] = v.w;
+                    }
+                } else if (vec_ok && f_addr + CW <= n_cigar) {
+#pragma unroll
+                    for (int q = 0; q < WPL; q += 4) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(cigar + f_addr + (uint64_t)lane * WPL + q);
+                        w[j][q] = v.x; w[j][q + 1] = v.y; w[j][q + 2] = v.z; w[j][q + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < WPL; q += 4) {
+                        uint32_t t4[4];
+                        depth_load4(cigar, n_cigar, vec_ok, f_addr + (uint64_t)lane * WPL + q, t4);
+                        w[j][q] = t4[0]; w[j][q + 1] = t4[1]; w[j][q + 2] = t4[2]; w[j][q + 3] = t4[3];
+                    }
+                }
             };
 #pragma unroll
-            for (int j = 0; j <= DEPTH_PF; j++) fetch(j);
+            for (int j = 0; j < NS; j++) fetch(j);
             int32_t base_rel = 0;                                                    // wave-uniform: position of the chunk's first word
             bool walking = true;
             while (walking) {
 #pragma unroll
-                for (int j = 0; j <= DEPTH_PF; j++) {
+                for (int j = 0; j < NS; j++) {
                     if (!walking) break;
                     if (!m_valid[j]) { walking = false; break; }                    // the stream has run dry (buffers are consumed in fetch order)
                     const uint32_t o0 = m_o0[j], nrem = m_nrem[j], c0rel = m_c0rel[j];      // word offset of this chunk from the item's first chunk
                     if (m_first[j]) base_rel = m_start[j];
-                    uint32_t (&cur)[4] = w[j];
+                    uint32_t (&cur)[WPL] = w[j];
                     // only the first and the last chunk of an item can hold words of a neighbouring read
-                    if (!(o0 >= c0rel && o0 + 4 * WAVE <= nrem)) {
-                        const uint32_t t = o0 + (uint32_t)lane * 4 - c0rel, lim = nrem - c0rel;      // word o is the item's iff o - c0rel < nrem - c0rel (unsigned)
+                    if (!(o0 >= c0rel && o0 + CW <= nrem)) {
+                        const uint32_t t = o0 + (uint32_t)lane * WPL - c0rel, lim = nrem - c0rel;      // word o is the item's iff o - c0rel < nrem - c0rel (unsigned)
 #pragma unroll
-                        for (int k = 0; k < 4; k++) if (!(t + k < lim)) cur[k] = (uint32_t)OP_P;
+                        for (int k = 0; k < WPL; k++) if (!(t + k < lim)) cur[k] = (uint32_t)OP_P;
                     }
                     // depth = (reads whose reference span covers the position) - (their D / N gaps over it): the same number as counting the
                     // aligned bases of every M / = / X run (cnv_caller.cpp:498-520), with HALF the difference-array updates on an ONT CIGAR
                     // (a gap op is every fourth op, an aligned run every second) and none of the run-end arithmetic: a gap covers
                     // [cursor before it, cursor after it), so its two updates sit at cursor values the walk computes anyway.
-                    uint32_t rl[4], gp[4], lane_ref = 0;
+                    uint32_t rl[WPL], gp[WPL], lane_ref = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < WPL; k++) {
                         // v_bfe_i32 takes its bit offset from the word's low five bits (op + the length's lowest bit): op masks repeated at bit 16
                         const uint32_t len = cur[k] >> 4;
                         rl[k] = len & (uint32_t)__builtin_amdgcn_sbfe((int)(REF_OPS | (REF_OPS << 16)), cur[k], 1u);    // all-ones when the op consumes the reference
@@ -546,7 +563,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                         // the whole chunk lies inside the tile (most do: a tile is seven chunks wide): cursors as byte offsets, no clipping
                         uint32_t a4 = (uint32_t)rel0 << 2;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < WPL; k++) {
                             const uint32_t n4 = lshl2_add(rl[k], a4);
                             if (gp[k]) {
                                 atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(diff) + a4), 0xffffffffu);
@@ -557,7 +574,7 @@ __global__ __launch_bounds__(DEPTH_THREADS, 8) void depth_tile_kernel(
                     } else {
                         int32_t rel = rel0, a = clamp0_i32(rel0, TW);
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < WPL; k++) {
                             rel += (int32_t)rl[k];
                             const int32_t b = clamp0_i32(rel, TW);
                             if (gp[k]) {                                       // (both ends clipped to the same edge cancel)
@@ -694,7 +711,13 @@ void launch_depth_tiles(hipStream_t s, const csv_reads &d, const uint32_t *ord, 
                        vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt, it, n_it)
     if (form == SCAN_FORM_ROWS16 || form == SCAN_FORM_LANES) { if (padded) CSV_TILE_LAUNCH(true, 16); else CSV_TILE_LAUNCH(false, 16); }
     else if (form == SCAN_FORM_ROWS8) { if (padded) CSV_TILE_LAUNCH(true, 8); else CSV_TILE_LAUNCH(false, 8); }
-    else { if (padded) CSV_TILE_LAUNCH(true, WAVE); else CSV_TILE_LAUNCH(false, WAVE); }
+    else {
+        static const int wpl = [] { const char *e = getenv("CSV_DEPTH_WPL"); return e && atoi(e) == 8 ? 8 : 4; }();
+        if (wpl == 8 && cigar_pad_words >= 8 * WAVE) {
+            hipLaunchKernelGGL((depth_tile_kernel<true, WAVE, 8>), dim3(tiles), dim3(DEPTH_THREADS), 0, s, d.n_reads, d.n_cigar, d.pos, d.flag, d.cigar_off, d.cigar,
+                               vec_ok, dvec_ok, ord, ref_end, tile_range, ckpt, depth_len, depth, cnt, it, n_it);
+        } else if (padded) CSV_TILE_LAUNCH(true, WAVE); else CSV_TILE_LAUNCH(false, WAVE);
+    }
 #undef CSV_TILE_LAUNCH
 }
 
