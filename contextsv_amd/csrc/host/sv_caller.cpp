@@ -647,6 +647,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         std::exception_ptr err;
         size_t regions = 0;
         bool pass_over = false;                            // (under mu) the CIGAR pass has returned: the task stops taking batches
+        bool prepare_over = false;                         // (under mu) the task is past prepare()
     } early;
     early.done.assign(n, 0);
     early.finished.assign(n, 0);
@@ -655,14 +656,20 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     const bool early_cn = P.cigar_svs && P.cigar_cn && P.split_svs && !P.save_cnv && n && lane_ctxs.size() > 1 && P.overlap_split_prepare && !env_on("CSV_NO_EARLY_CN");
     std::unique_ptr<SplitSetup> split;
     csvhost::WorkerThreads::Ticket split_task = nullptr;
+    const bool forced_batches = env_on("CSV_EARLY_CN_WAIT_ALL") || env_on("CSV_EARLY_SMALL_BATCHES");       // (tests)
     if (P.split_svs) {
         split = makeSplitSetup(contigs, P);
         if (P.cigar_svs && n && lane_ctxs.size() > 1 && P.overlap_split_prepare) {
             SplitSetup *S = split.get();
-            split_task = csvhost::WorkerThreads::instance().start([&, S] {
+            split_task = csvhost::WorkerThreads::instance().start([&, S, forced_batches] {
                 const double t0 = now_ms();
                 try { S->pass->prepare(); } catch (...) { S->err = std::current_exception(); }
                 S->ms_prepare = now_ms() - t0;
+                {   // prepare() outlasted the CIGAR pass (short reads): the run has gone on without waiting and no batch may be taken any more
+                    std::lock_guard<std::mutex> l(early.mu);
+                    early.prepare_over = true;
+                    if (early.pass_over && !forced_batches) return;
+                }
                 if (!early_cn || S->err) return;
                 try {
                     if (env_on("CSV_EARLY_CN_WAIT_ALL")) {                      // tests: every contig through this path, whatever the timing
@@ -773,6 +780,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         EarlyCn &e;
         ~EndPass() { std::lock_guard<std::mutex> l(e.mu); e.pass_over = true; }
     } end_pass{early};
+    bool join_later = false;
     if (P.cigar_svs && n) {
         csvhost::TraceScope tr_pass("run: CIGAR pass");
         if (L == 1) {
@@ -786,9 +794,11 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
             processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats, note, min_mapq, min_oplen);
         }
         T.ms_cigar = now_ms() - t_begin;
-        { std::lock_guard<std::mutex> l(early.mu); early.pass_over = true; }
-        // (the early copy-number batch works on lane_calls in place: it must be over before they move)
-        if (split_task) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
+        // (the early copy-number batch works on lane_calls in place: it must be over before they move. A task still inside prepare()
+        // takes no batch after the pass: the run goes on — the CIGAR copy-number pass needs nothing of prepare() — and meets the task in
+        // front of the split chain.)
+        { std::lock_guard<std::mutex> l(early.mu); early.pass_over = true; join_later = split_task && !early.prepare_over && !forced_batches && !env_on("CSV_NO_LATE_JOIN"); }
+        if (split_task && !join_later) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
         for (size_t l = 0; l < L; l++)
             for (size_t k = 0; k < which[l].size(); k++) { per[which[l][k]] = std::move(lane_calls[l][k]); stats[which[l][k]] = lane_stats[l][k]; }
     } else T.ms_cigar = now_ms() - t_begin;
@@ -796,13 +806,16 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         T.n_signatures += stats[i].n_signatures; T.n_cigar_calls += per[i].size(); T.n_reads += contigs[i].split.n;
         whole_genome_sv_calls[contigs[i].name] = std::move(per[i]);
     }
-    if (split_task) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
-    if (split && split->err) std::rethrow_exception(split->err);
-    if (early.err) std::rethrow_exception(early.err);
-    T.n_cigar_cn_regions += early.regions;
+    const std::function<void()> join = [&] {
+        if (split_task) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
+        if (split && split->err) std::rethrow_exception(split->err);
+        if (early.err) std::rethrow_exception(early.err);
+    };
+    if (!join_later) join();
+    T.n_cigar_cn_regions += early.regions;                                  // (a task joined later has taken no batch)
     T.n_split_calls += early.n_split_calls;
     finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get(), lane_ctxs.size() > 1 ? lane_ctxs[0] : nullptr, early_cn ? &early.done : nullptr,
-              early_cn ? &early.finished : nullptr);
+              early_cn ? &early.finished : nullptr, join_later ? &join : nullptr);
     T.ms_total = now_ms() - t_begin;
     if (stats_out) *stats_out = stats;
     if (times) *times = T;
@@ -834,7 +847,7 @@ std::unique_ptr<SVCaller::SplitSetup> SVCaller::makeSplitSetup(std::vector<Resid
 
 void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
                          std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split, csv_ctx *side_ctx,
-                         const std::vector<char> *cigar_cn_done, const std::vector<char> *finished)
+                         const std::vector<char> *cigar_cn_done, const std::vector<char> *finished, const std::function<void()> *before_split)
 {
     const EmptySnps no_snps;
     csvhost::WorkerThreads::Ticket teardown = nullptr;
@@ -904,6 +917,7 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         if (!split) { own = makeSplitSetup(contigs, P); split = own.get(); }
         T.ms_split_fetch = 0.0;
         std::unordered_map<std::string, std::vector<SVCall>> split_calls;
+        if (before_split) (*before_split)();                                       // (prepare() still running on its thread: meet it here)
         split->pass->finish(split_calls);                                          // (runs prepare() first when nobody has)
         T.ms_split_prepare = split->ms_prepare;
         {   // the pass's working set (1e5 small vectors for a genome) is torn down beside the next stages, not between them

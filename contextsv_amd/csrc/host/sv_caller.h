@@ -188,7 +188,8 @@ private:
     void finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
                    std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split = nullptr,
                    csv_ctx *side_ctx = nullptr, const std::vector<char> *cigar_cn_done = nullptr /* per contig: CIGAR copy-number predictions already made */,
-                   const std::vector<char> *finished = nullptr /* per contig: every stage already made (its entry of the call map is final) */);
+                   const std::vector<char> *finished = nullptr /* per contig: every stage already made (its entry of the call map is final) */,
+                   const std::function<void()> *before_split = nullptr /* called in front of the split chain: joins a prepare() still running */);
     struct DeviceOut {                       // what the device chain of one shard hands to the host merge: page-locked result buffers
         csv_ctx *ctx = nullptr;
         csv_sig *sig = nullptr;
