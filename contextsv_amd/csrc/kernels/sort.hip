@@ -203,11 +203,138 @@ static int rs_rounds_for(uint64_t n)
     return rounds;
 }
 
+// ---- the same passes in ONE launch each ("onesweep": Adinets & Merrill) ---------------------------------------------------------------
+// The three launches of a pass exist to turn per-tile digit counts into global offsets. A digit's base (how many keys have a smaller
+// digit) does not depend on the order of the keys: ONE kernel counts all passes' digits up front. What remains — how many keys of MY
+// digit sit in the tiles before mine — a workgroup gets by looking back over its predecessors' published counts: a status word per
+// (tile, digit) carries a 2-bit state (nothing yet / this tile's own count / the inclusive count up to this tile) and a 30-bit
+// value in ONE 32-bit store, so no fence is needed; thread d walks digit d's column backwards until it meets an inclusive count.
+// Tiles are handed out by an atomic counter in the order the workgroups START, so every predecessor of a running workgroup is itself
+// running (or done): the look-back always terminates. (Belt and braces: a poll count bounds every wait — a pass can produce garbage,
+// flagged in `err`, but never hang the device.) A workgroup = 4 waves = 4 consecutive wave tiles of the three-launch form, walked the
+// same way (round-major, 8-ballot match-any ranks, per-wave cursors in LDS): the output is the same stable order, bit for bit.
+// 24 contigs' split order: 33 passes = 99 launches (and a one-workgroup table scan of ~78 us beside the big kernels each) -> 33 + 7.
+constexpr uint32_t OS_AGG = 1u << 30, OS_INC = 2u << 30, OS_VAL = (1u << 30) - 1;
+constexpr int OS_MAX_PASSES = 8;
+constexpr uint32_t OS_SPIN_LIMIT = 1u << 24;
+
+__global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n, int passes, uint32_t *__restrict__ ghist)
+{
+    __shared__ uint32_t h[OS_MAX_PASSES][RS_BINS];
+    for (int p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RS_THREADS) {
+        const uint64_t k = keys[i];
+        for (int p = 0; p < passes; p++) atomicAdd(&h[p][(uint32_t)(k >> (p * RS_BITS)) & (RS_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; p++) {
+        const uint32_t v = h[p][threadIdx.x];
+        if (v) atomicAdd(&ghist[p * RS_BINS + threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t n, int shift,
+                                                            const uint32_t *__restrict__ ghist, uint32_t *status, uint32_t *counter, uint32_t *err,
+                                                            uint32_t n_tiles, int rounds, uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out)
+{
+    static_assert(RS_THREADS == RS_BINS, "one thread per digit");
+    __shared__ uint32_t offs[RS_WAVES][RS_BINS];
+    __shared__ uint32_t wsum[RS_WAVES];
+    __shared__ uint32_t s_tile;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_tile = atomicAdd(counter, 1u);
+    for (int b = lane; b < RS_BINS; b += WAVE) offs[wave][b] = 0;
+    __syncthreads();
+    const uint32_t wg_tile = s_tile;
+    const uint64_t tile = (uint64_t)wg_tile * RS_WAVES + wave;
+    const uint64_t t0 = tile * (uint64_t)rounds * WAVE;
+    if (tile < n_tiles) {
+        for (int rd = 0; rd < rounds; rd++) {
+            const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
+            if (i < n) atomicAdd(&offs[wave][(uint32_t)(keys_in[i] >> shift) & (RS_BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t d = threadIdx.x;                                    // this thread's digit
+        uint32_t c[RS_WAVES], tot = 0;
+        for (int w = 0; w < RS_WAVES; w++) { c[w] = offs[w][d]; tot += c[w]; }
+        uint32_t *st = status + (uint64_t)wg_tile * RS_BINS + d;
+        __hip_atomic_store(st, (wg_tile == 0 ? OS_INC : OS_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // keys with a smaller digit: exclusive sum over the 256 digit totals
+        const uint32_t g = ghist[d];
+        const uint32_t incl = wave_incl_sum_dpp(g);
+        if (lane == WAVE - 1) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - g;
+        for (int w = 0; w < wave; w++) base += wsum[w];
+        // keys of this digit in the tiles before this one
+        uint32_t excl = 0;
+        if (wg_tile > 0) {
+            uint32_t j = wg_tile - 1, spins = 0;
+            for (;;) {
+                const uint32_t v = __hip_atomic_load(status + (uint64_t)j * RS_BINS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t f = v >> 30;
+                if (f == 0) {
+                    if (++spins > OS_SPIN_LIMIT) { *err = 1u; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += v & OS_VAL;
+                if (f == 2 || j == 0) break;
+                j--;
+            }
+            __hip_atomic_store(st, OS_INC | ((excl + tot) & OS_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t o = base + excl;
+        for (int w = 0; w < RS_WAVES; w++) { offs[w][d] = o; o += c[w]; }
+    }
+    __syncthreads();
+    if (tile >= n_tiles) return;
+    const uint64_t lt = lanemask_lt();
+    for (int rd = 0; rd < rounds; rd++) {
+        const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
+        const bool valid = i < n;
+        uint64_t key = 0; uint32_t val = 0;
+        if (valid) { key = keys_in[i]; val = vals_in[i]; }
+        const uint32_t d = (uint32_t)(key >> shift) & (uint32_t)(RS_BINS - 1);
+        uint64_t mask = __ballot(valid);
+        if (mask == 0) break;
+#pragma unroll
+        for (int b = 0; b < RS_BITS; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        uint32_t base = 0;
+        if (valid) base = offs[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rank = (uint32_t)__popcll(mask & lt);
+        if (valid && rank == 0) offs[wave][d] = base + (uint32_t)__popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) { keys_out[base + rank] = key; vals_out[base + rank] = val; }
+    }
+}
+
+static uint64_t os_wg_tiles_max(uint64_t n)       // workgroup tiles of the largest table a sort of n keys can need (smallest tile above 128 wave tiles)
+{
+    const uint64_t big = (n + (uint64_t)RS_ROUNDS * WAVE * RS_WAVES - 1) / ((uint64_t)RS_ROUNDS * WAVE * RS_WAVES);
+    return std::max<uint64_t>(big, 64) + 1;
+}
+static size_t os_tmp_bytes(uint64_t n) { return 256 + align_up((size_t)OS_MAX_PASSES * RS_BINS * 4, 256) + (size_t)OS_MAX_PASSES * os_wg_tiles_max(n) * RS_BINS * 4; }
+
+static bool onesweep_on()
+{
+    const char *e = getenv("CSV_SORT_ONESWEEP");                                  // "0": the three-launch passes (A/B, tests)
+    return !(e && *e == '0');
+}
+
 size_t radix_sort_tmp_bytes(uint64_t n)
 {
     const uint64_t n_tiles = (n + 2 * WAVE - 1) / (2 * WAVE);         // upper bound (smallest tile)
     const uint64_t tab = (uint64_t)RS_BINS * (n_tiles ? n_tiles : 1);
-    return align_up(tab * sizeof(uint32_t), 256) + exclusive_sum_tmp_bytes(tab);
+    return std::max(align_up(tab * sizeof(uint32_t), 256) + exclusive_sum_tmp_bytes(tab), os_tmp_bytes(n));
 }
 
 int launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_out, uint32_t *vals_out,
@@ -224,6 +351,23 @@ int launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, u
     const int passes = (key_bits + RS_BITS - 1) / RS_BITS;
     uint64_t *ki = keys_in, *ko = keys_out;
     uint32_t *vi = vals_in, *vo = vals_out;
+    if (onesweep_on() && n < (1ull << 30) && passes <= OS_MAX_PASSES && grid + 1 <= os_wg_tiles_max(n)) {
+        // [0, 256): tile counters (one per pass) and the error flag; digit totals of every pass; status words of every pass
+        uint32_t *counters = (uint32_t *)tmp, *err = counters + OS_MAX_PASSES;
+        uint32_t *ghist = (uint32_t *)((char *)tmp + 256);
+        uint32_t *status = (uint32_t *)((char *)ghist + align_up((size_t)OS_MAX_PASSES * RS_BINS * 4, 256));
+        const size_t used = 256 + align_up((size_t)OS_MAX_PASSES * RS_BINS * 4, 256) + (size_t)passes * grid * RS_BINS * 4;
+        (void)hipMemsetAsync(tmp, 0, used, s);
+        const unsigned hgrid = (unsigned)std::min<uint64_t>((n + 8 * RS_THREADS - 1) / (8 * RS_THREADS), 1024);
+        hipLaunchKernelGGL(os_hist_kernel, dim3(hgrid), dim3(RS_THREADS), 0, s, ki, n, passes, ghist);
+        for (int p = 0; p < passes; p++) {
+            hipLaunchKernelGGL(os_pass_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, vi, n, p * RS_BITS, ghist + p * RS_BINS, status + (size_t)p * grid * RS_BINS,
+                               counters + p, err, n_tiles, rounds, ko, vo);
+            uint64_t *tk = ki; ki = ko; ko = tk;
+            uint32_t *tv = vi; vi = vo; vo = tv;
+        }
+        return (passes & 1) ? 1 : 0;
+    }
     for (int p = 0; p < passes; p++) {
         const int shift = p * RS_BITS;
         hipLaunchKernelGGL(rs_hist_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, n, shift, table, n_tiles, rounds);
