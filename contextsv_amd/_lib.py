@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSVGPU_LIB: another build of the same library (tests: lib/libcsvgpu_testhooks.so, which also exports the allocation-failure hook)
 LIB_PATH = os.environ.get("CSVGPU_LIB") or os.path.join(_HERE, "lib", "libcsvgpu.so")
-ABI_VERSION = 2          # include/csvgpu.h CSVGPU_ABI_VERSION
+ABI_VERSION = 3          # include/csvgpu.h CSVGPU_ABI_VERSION
 
 CSV_OK, CSV_EINVAL, CSV_ENODEV, CSV_ENOMEM, CSV_EHIP, CSV_ECAPACITY = 0, -1, -2, -3, -4, -5
 STATUS_NAMES = {0: "CSV_OK", -1: "CSV_EINVAL", -2: "CSV_ENODEV", -3: "CSV_ENOMEM", -4: "CSV_EHIP", -5: "CSV_ECAPACITY"}
@@ -90,6 +90,7 @@ ABI = {
     "csvgpu_shard_set_qname_hash": (C.c_int, [_P, _P, _P]),
     "csvgpu_split_order": (C.c_int, [_P, C.c_int, _P, C.c_uint8, _P, C.c_uint64, _P, C.c_uint64, _P]),
     "csvgpu_split_order_begin": (C.c_int, [_P, C.c_int, _P, C.c_uint8]),
+    "csvgpu_split_order_begin_self": (C.c_int, [_P, C.c_int, _P, C.c_uint8]),
     "csvgpu_split_order_finish": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _P]),
     "csvgpu_window_log2_resident": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_double, _P, _P, _P]),
     "csvgpu_window_log2_resident_many": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -215,6 +215,22 @@ class Context:
         self._check(rc)
         return [out[int(off[k]): int(off[k + 1])].copy() for k in range(n)]
 
+    def split_order_self(self, shards, min_mapq: int, capacity: int = 4):
+        """csvgpu_split_order_begin_self (the supplementary hashes are those of the same shards' supplementary records; the whole order is
+        queued) + csvgpu_split_order_finish without hashes."""
+        n = len(shards)
+        hs = (C.c_void_p * max(n, 1))(*[s.h for s in shards])
+        self._check(self.lib.csvgpu_split_order_begin_self(self.h, n, hs, min_mapq))
+        out = np.zeros(max(capacity, 1), np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        rc = self.lib.csvgpu_split_order_finish(self.h, None, 0, ptr(out), capacity, ptr(off))
+        if rc == _lib.CSV_ECAPACITY:
+            capacity = int(off[n])
+            out = np.zeros(max(capacity, 1), np.uint32)
+            rc = self.lib.csvgpu_split_order_finish(self.h, None, 0, ptr(out), capacity, ptr(off))
+        self._check(rc)
+        return [out[int(off[k]): int(off[k + 1])].copy() for k in range(n)]
+
     # -------------------------------------------------------------------------------- timing
     def synchronize(self):
         self._check(self.lib.csvgpu_synchronize(self.h))

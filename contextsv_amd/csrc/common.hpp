@@ -200,6 +200,8 @@ size_t radix_sort_tmp_bytes(uint64_t n);
 // result is in keys_out/vals_out, 0 when it is in keys_in/vals_in (even number of passes).
 int  launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_out, uint32_t *vals_out,
                            uint64_t n, int key_bits, void *tmp);
+int  launch_radix_sort_u64_devn(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_out, uint32_t *vals_out, uint64_t n_bound,
+                                const uint32_t *n_dev, int key_bits, void *tmp);
 // bucket ordering: BK_N most-significant-digit buckets + one wave ranking each bucket; see sort.hip
 constexpr uint32_t BK_BITS = 14, BK_N = 1u << BK_BITS, BK_LOCAL_MAX = 2048;
 // (the bucket counts come from the scan: ScanExtras::bucket_hist)
@@ -278,12 +280,14 @@ void launch_st_survivors(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes
 void launch_st_member(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, int j, const uint64_t *node_hash, const uint32_t *bitmap_prev, uint32_t *bitmap_next,
                       uint32_t *set, unsigned int *count);
 void launch_st_inverse(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, int j_last, const uint32_t *list, uint32_t *prevrank);
-void launch_st_mint(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint64_t *node_hash, const uint32_t *prevrank, uint32_t *minT);
-void launch_st_keys(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint64_t *node_hash, const uint32_t *prevrank, const uint32_t *minT,
-                    uint64_t *keys, uint32_t *vals);
-void launch_st_rank(hipStream_t s, const uint32_t *vals, uint32_t n, uint32_t *prevrank);
-void launch_st_emit(hipStream_t s, const SplitTailHost &h, const uint32_t *vals, uint32_t n, const uint8_t *is_surv, const uint32_t *node_rec, csv_split_survivor *out,
-                    uint64_t cap, unsigned long long *count);
+void launch_st_mint(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint32_t *n_dev, const uint64_t *node_hash, const uint32_t *prevrank,
+                    uint32_t *minT);
+void launch_st_keys(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint32_t *n_dev, const uint64_t *node_hash, const uint32_t *prevrank,
+                    const uint32_t *minT, uint64_t *keys, uint32_t *vals);
+void launch_st_rank(hipStream_t s, const uint32_t *vals, uint32_t n, const uint32_t *n_dev, uint32_t *prevrank);
+void launch_st_emit(hipStream_t s, const SplitTailHost &h, const uint32_t *vals, uint32_t n, const uint32_t *n_dev, const uint8_t *is_surv, const uint32_t *node_rec,
+                    csv_split_survivor *out, uint64_t cap, unsigned long long *count);
+void launch_so_supp(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, uint64_t *supp_hash, unsigned int *count);
 // dbscan1d.hip
 void launch_dbscan_1d_batched(hipStream_t s, const int32_t *pts, const uint64_t *seg_off, uint64_t n_seg,
                               double eps, int min_pts, int32_t *labels, unsigned int *too_large_flag);

@@ -1124,6 +1124,8 @@ struct csv_split_state {
     uint8_t *is_surv = nullptr;
     size_t bm_words = 0;
     bool finished = false;
+    bool self = false;                 // the supplementary hashes are taken from the same shards: the whole order was queued by _begin
+    uint64_t self_bound = 0;           // survivors the page-locked block has room for (self)
     std::vector<csv_split_survivor> surv;
     std::vector<uint64_t> off;
 };
@@ -1131,7 +1133,9 @@ struct csv_split_state {
 static void split_state_free(csv_ctx *ctx) { if (ctx) { delete ctx->split_state; ctx->split_state = nullptr; } }
 
 // nodes + every epoch that does not depend on the supplementary records: queued, not waited for (beyond the node counts)
-static int split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq, int64_t n_supp_hint /* < 0: unknown */)
+static int split_order_tail(csv_ctx *ctx, csv_split_state *st, const uint64_t *d_supp, uint64_t n_supp, bool devn);
+
+static int split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq, int64_t n_supp_hint /* < 0: unknown */, bool self = false)
 {
     if (!ctx) return CSV_EINVAL;
     delete ctx->split_state; ctx->split_state = nullptr;
@@ -1165,21 +1169,35 @@ static int split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shar
     int rc = arena_reserve(ctx, ctx->arena, align_up((n_blocks + 1) * 4, 256) + exclusive_sum_tmp_bytes(n_blocks + 1) + align_up(total_reads * 8, 256) +
                                                 2 * align_up(total_reads * 4, 256) + align_up(total_reads * 8, 256) + 4096);
     if (rc) return rc;
+    unsigned int *d_nsupp = (unsigned int *)arena_alloc(ctx->arena, 256);
     uint32_t *blk = (uint32_t *)arena_alloc(ctx->arena, (n_blocks + 1) * 4);
     void *es_tmp = arena_alloc(ctx->arena, exclusive_sum_tmp_bytes(n_blocks + 1));
     uint64_t *node_hash = (uint64_t *)arena_alloc(ctx->arena, total_reads * 8);
     uint32_t *node_rec = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4), *list = (uint32_t *)arena_alloc(ctx->arena, total_reads * 4);
     st->d_supp = (uint64_t *)arena_alloc(ctx->arena, total_reads * 8);
-    if (!blk || !es_tmp || !node_hash || !node_rec || !list || !st->d_supp) { ctx->err = "arena exhausted (split order)"; return CSV_ENOMEM; }
+    if (!d_nsupp || !blk || !es_tmp || !node_hash || !node_rec || !list || !st->d_supp) { ctx->err = "arena exhausted (split order)"; return CSV_ENOMEM; }
     st->node_hash = node_hash; st->node_rec = node_rec; st->list = list;
     CSV_HIP(ctx, hipMemsetAsync(blk + n_blocks, 0, 4, s));
     launch_so_count(s, tab, (uint32_t)n_blocks, min_mapq, blk);
     launch_exclusive_sum_u32(s, blk, n_blocks + 1, es_tmp);
     launch_so_scatter(s, tab, (uint32_t)n_blocks, min_mapq, blk, node_hash, node_rec);
-    if ((rc = ensure_pinned(ctx, (n_blocks + 1) * 4 + 64))) return rc;
+    if ((rc = ensure_pinned(ctx, (n_blocks + 1) * 4 + 64 + 256))) return rc;
     CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, blk, (n_blocks + 1) * 4, hipMemcpyDeviceToHost, s));
+    const size_t nsupp_at = align_up((n_blocks + 1) * 4, 64);
+    if (self) {                                  // the supplementary records' hashes of the same shards (their count comes back with the node counts)
+        CSV_HIP(ctx, hipMemsetAsync(d_nsupp, 0, 4, s));
+        launch_so_supp(s, tab, (uint32_t)n_blocks, min_mapq, st->d_supp, d_nsupp);
+        CSV_HIP(ctx, hipMemcpyAsync((char *)ctx->pinned + nsupp_at, d_nsupp, 4, hipMemcpyDeviceToHost, s));
+    }
     CSV_HIP(ctx, wait_stream(s));
     const uint32_t *h_blk = (const uint32_t *)ctx->pinned;
+    uint64_t n_supp_self = 0;
+    if (self) {
+        n_supp_self = *(const uint32_t *)((const char *)ctx->pinned + nsupp_at);
+        n_supp_hint = (int64_t)n_supp_self;
+        st->self = true;
+        if (n_supp_self == 0) { st->finished = true; ctx->split_state = st.release(); return CSV_OK; }          // nothing survives
+    }
     std::vector<uint64_t> &N = st->N;
     N.assign((size_t)n_contigs, 0);
     uint64_t n_nodes = h_blk[n_blocks], n_max = 0;
@@ -1207,7 +1225,7 @@ static int split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shar
     }
     SplitTailHost &th = st->th;
     th.A = (uint32_t)n_contigs; th.wv = std::max(1, bits_of(n_nodes)); th.wa = std::max(1, bits_of((uint64_t)n_contigs - 1));
-    if (n_nodes >= (1ull << 31) || th.wa + 2 * (th.wv + 1) > 64) D = 0;
+    if (n_nodes >= (1ull << 31) || th.wa + 2 * (th.wv + 1) > 64 || (self && n_nodes >= (1ull << 30))) D = 0;      // (self: the queued sorts count in 30 bits)
     th.D = (uint32_t)D;
     std::vector<int> K((size_t)n_contigs, -1);                       // a contig's last epoch
     for (int c = 0; c < n_contigs; c++) {
@@ -1238,12 +1256,13 @@ static int split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shar
         scratch = std::max(scratch, A * buckets[k] * 4);
     }
     const size_t bm_words = st->bm_words = (size_t)((tail_buckets + 31) / 32 + 8);
-    if ((rc = arena_reserve(ctx, ctx->work, align_up(scratch + 16, 256) + sortws_bytes(n_nodes) + align_up(n_nodes * sizeof(csv_split_survivor), 256) +
+    const uint64_t n_sort = std::max(n_nodes, n_supp_self);
+    if ((rc = arena_reserve(ctx, ctx->work, align_up(scratch + 16, 256) + sortws_bytes(n_sort) + align_up(n_nodes * sizeof(csv_split_survivor), 256) +
                                                 (size_t)D * (align_up(bm_words * 4, 256) + align_up(n_nodes * 4, 256)) + align_up(n_nodes, 256) + align_up(n_nodes * 4, 256) +
                                                 align_up(st_filter_bytes(), 256) + 8192))) return rc;
     uint32_t *minT = st->minT = (uint32_t *)arena_alloc(ctx->work, scratch + 16);
     SortWs &w = st->w;
-    if (!minT || !sortws_carve(ctx->work, n_nodes, w)) { ctx->err = "arena exhausted (split order epochs)"; return CSV_ENOMEM; }
+    if (!minT || !sortws_carve(ctx->work, n_sort, w)) { ctx->err = "arena exhausted (split order epochs)"; return CSV_ENOMEM; }
     st->d_out = (csv_split_survivor *)arena_alloc(ctx->work, n_nodes * sizeof(csv_split_survivor));
     st->d_count = (unsigned long long *)arena_alloc(ctx->work, 256);      // [0] survivors; 32-bit set sizes from byte 64 on
     if (!st->d_out || !st->d_count) { ctx->err = "arena exhausted (split order survivors)"; return CSV_ENOMEM; }
@@ -1305,8 +1324,73 @@ static int split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shar
         launch_so_setlist(s, e, M, io ? w.v1 : w.v0, list);
     }
     if (D > 0) launch_st_inverse(s, th, (uint32_t)n_nodes, D - 1, list, st->prevrank);
+    if (self) {
+        // everything else too: the hashes sorted (64-bit keys, the values are not used), the survivors-only levels with the set sizes read on
+        // the device, the survivors copied to the page-locked block — _finish only waits
+        const int io = launch_radix_sort_u64(s, st->d_supp, w.v0, w.k1, w.v1, n_supp_self, 64, w.tmp);
+        if (io != 0) { ctx->err = "split_order: unexpected sort parity"; return CSV_EHIP; }
+        if ((rc = split_order_tail(ctx, st.get(), st->d_supp, n_supp_self, true))) return rc;
+        st->self_bound = std::min<uint64_t>(n_supp_self, n_nodes);
+        if ((rc = ensure_pinned(ctx, 64 + st->self_bound * sizeof(csv_split_survivor) + 64))) return rc;
+        CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, st->d_count, 8, hipMemcpyDeviceToHost, s));
+        CSV_HIP(ctx, hipMemcpyAsync((char *)ctx->pinned + 64, st->d_out, st->self_bound * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
+    }
     if (hipGetLastError() != hipSuccess) { ctx->err = "split_order: launch failed"; return CSV_EHIP; }
     ctx->split_state = st.release();
+    return CSV_OK;
+}
+
+// the survivors in their final order: the last D epochs for them and the nodes their order depends on (or, D = 0, the chain's final
+// positions). devn: the set sizes stay on the device (everything is queued, nothing waited for).
+static int split_order_tail(csv_ctx *ctx, csv_split_state *st, const uint64_t *d_supp, uint64_t n_supp, bool devn)
+{
+    hipStream_t s = ctx->stream;
+    const int D = st->D;
+    const int n_contigs = st->n_contigs;
+    SplitTailHost &th = st->th;
+    SortWs &w = st->w;
+    const uint64_t n_nodes = st->n_nodes, cap = n_nodes;
+    if (D == 0) {
+        // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
+        launch_so_survivors(s, st->tab, n_nodes, st->node_hash, st->node_rec, st->list, d_supp, n_supp, st->d_out, cap, st->d_count);
+        return CSV_OK;
+    }
+    // ---- top-down: who takes part in the last D epochs (hashes only) ----
+    unsigned int *d_setn = (unsigned int *)((char *)st->d_count + 64);
+    uint32_t set_n[SO_TAIL_MAX + 1] = {0, 0, 0, 0};
+    for (int j = 0; j < D; j++) CSV_HIP(ctx, hipMemsetAsync(st->bitmap[j], 0, st->bm_words * 4, s));
+    CSV_HIP(ctx, hipMemsetAsync(st->filter, 0, st_filter_bytes(), s));
+    launch_st_survivors(s, th, (uint32_t)n_nodes, st->node_hash, d_supp, n_supp, st->filter, st->is_surv, st->bitmap[0]);
+    for (int j = 1; j <= D; j++)
+        launch_st_member(s, th, (uint32_t)n_nodes, j, st->node_hash, st->bitmap[j - 1], j < D ? st->bitmap[j] : nullptr, st->set[j], d_setn + j);
+    if (!devn) {
+        CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_setn, 16, hipMemcpyDeviceToHost, s));
+        CSV_HIP(ctx, wait_stream(s));
+        for (int j = 1; j <= D; j++) set_n[j] = ((const uint32_t *)ctx->pinned)[j];
+        // a t value is a list position or an insertion index (below the largest contig's node count) or a rank in a level's order (below the set's size)
+        uint64_t t_max = st->n_max;
+        for (int j = 1; j <= D; j++) t_max = std::max<uint64_t>(t_max, set_n[j]);
+        th.wv = std::max(1, bits_of(t_max));
+    } else {
+        for (int j = 1; j <= D; j++) set_n[j] = (uint32_t)n_nodes;           // (bounds: the kernels read the sizes)
+        th.wv = std::max(1, bits_of(n_nodes));
+    }
+    // ---- bottom-up: order S_D with the chain's positions, then each smaller set with the ranks of the order before ----
+    const int key_bits = th.wa + 2 * (th.wv + 1);
+    for (int j = D - 1; j >= 0; j--) {
+        const uint32_t n = set_n[j + 1];
+        const uint32_t *n_dev = devn ? d_setn + (j + 1) : nullptr;
+        if (n == 0) continue;
+        CSV_HIP(ctx, hipMemsetAsync(st->minT, 0xff, (size_t)th.boff[j][n_contigs] * 4, s));
+        launch_st_mint(s, th, j, st->set[j + 1], n, n_dev, st->node_hash, st->prevrank, st->minT);
+        launch_st_keys(s, th, j, st->set[j + 1], n, n_dev, st->node_hash, st->prevrank, st->minT, w.k0, w.v0);
+        const int io = devn ? launch_radix_sort_u64_devn(s, w.k0, w.v0, w.k1, w.v1, n, n_dev, key_bits, w.tmp)
+                            : launch_radix_sort_u64(s, w.k0, w.v0, w.k1, w.v1, n, key_bits, w.tmp);
+        if (io < 0) { ctx->err = "split_order: set too large for the queued sort"; return CSV_EINVAL; }
+        const uint32_t *sorted = (devn || n > 1) ? (io ? w.v1 : w.v0) : w.v0;
+        if (j > 0) launch_st_rank(s, sorted, n, n_dev, st->prevrank);
+        else launch_st_emit(s, th, sorted, n, n_dev, st->is_surv, st->node_rec, st->d_out, cap, st->d_count);
+    }
     return CSV_OK;
 }
 
@@ -1316,12 +1400,13 @@ static int split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t 
     csv_split_state *st = ctx->split_state;
     if (!st) { ctx->err = "split_order_finish without split_order_begin"; return CSV_EINVAL; }
     const int n_contigs = st->n_contigs;
-    if (!out_off || (n_supp && !supp_hash) || (capacity && !out_rec)) { ctx->err = "split_order: null array"; return CSV_EINVAL; }
-    for (uint64_t i = 1; i < n_supp; i++) if (supp_hash[i] <= supp_hash[i - 1]) { ctx->err = "split_order: supp_hash must be sorted and distinct"; return CSV_EINVAL; }
+    if (!out_off || (!st->self && n_supp && !supp_hash) || (capacity && !out_rec)) { ctx->err = "split_order: null array"; return CSV_EINVAL; }
+    if (!st->self)
+        for (uint64_t i = 1; i < n_supp; i++) if (supp_hash[i] <= supp_hash[i - 1]) { ctx->err = "split_order: supp_hash must be sorted and distinct"; return CSV_EINVAL; }
     for (int c = 0; c <= n_contigs; c++) out_off[c] = 0;
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    if (!st->finished) {
+    if (!st->finished && !st->self) {
         if (n_supp == 0) {               // nothing survives
             CSV_HIP(ctx, wait_stream(s));
             st->finished = true;
@@ -1329,66 +1414,42 @@ static int split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t 
     }
     if (!st->finished) {
         TimerScope ts(ctx, CSV_K_SPLIT_ORDER);
-        const int D = st->D;
-        SplitTailHost &th = st->th;
-        SortWs &w = st->w;
-        const uint64_t n_nodes = st->n_nodes, cap = n_nodes;
-        // (room for one hash per record of these contigs was set aside by _begin; a run's other contigs can add more)
-        struct TmpBuf { void *p = nullptr; ~TmpBuf() { if (p) (void)hipFree(p); } } big_supp;
-        uint64_t *d_supp = st->d_supp;
-        if (n_supp > st->total_reads) {
-            if (hipMalloc(&big_supp.p, n_supp * 8) != hipSuccess) { (void)hipGetLastError(); big_supp.p = nullptr; ctx->err = "hipMalloc failed (supplementary hashes)"; return CSV_ENOMEM; }
-            d_supp = (uint64_t *)big_supp.p;
-        }
-        // (through the context's page-locked block: a pageable copy is staged by the runtime under a lock the lanes' launches also take)
-        int prc = ensure_pinned(ctx, std::max<size_t>(n_supp * 8, 4096) + 64);
-        if (prc) return prc;
-        memcpy(ctx->pinned, supp_hash, n_supp * 8);
-        CSV_HIP(ctx, hipMemcpyAsync(d_supp, ctx->pinned, n_supp * 8, hipMemcpyHostToDevice, s));
-        CSV_HIP(ctx, wait_stream(s));                    // (the block is reused for the set sizes below)
-        if (D == 0) {
-            // ---- survivors: nodes whose name hash is a supplementary record's; their final position orders them ----
-            launch_so_survivors(s, st->tab, n_nodes, st->node_hash, st->node_rec, st->list, d_supp, n_supp, st->d_out, cap, st->d_count);
-        } else {
-            // ---- top-down: who takes part in the last D epochs (hashes only) ----
-            unsigned int *d_setn = (unsigned int *)((char *)st->d_count + 64);
-            uint32_t set_n[SO_TAIL_MAX + 1] = {0, 0, 0, 0};
-            for (int j = 0; j < D; j++) CSV_HIP(ctx, hipMemsetAsync(st->bitmap[j], 0, st->bm_words * 4, s));
-            CSV_HIP(ctx, hipMemsetAsync(st->filter, 0, st_filter_bytes(), s));
-            launch_st_survivors(s, th, (uint32_t)n_nodes, st->node_hash, d_supp, n_supp, st->filter, st->is_surv, st->bitmap[0]);
-            for (int j = 1; j <= D; j++)
-                launch_st_member(s, th, (uint32_t)n_nodes, j, st->node_hash, st->bitmap[j - 1], j < D ? st->bitmap[j] : nullptr, st->set[j], d_setn + j);
-            CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_setn, 16, hipMemcpyDeviceToHost, s));
-            CSV_HIP(ctx, wait_stream(s));
-            for (int j = 1; j <= D; j++) set_n[j] = ((const uint32_t *)ctx->pinned)[j];
-            // ---- bottom-up: order S_D with the chain's positions, then each smaller set with the ranks of the order before ----
-            // a t value is a list position or an insertion index (below the largest contig's node count) or a rank in a level's order (below the set's size)
-            uint64_t t_max = st->n_max;
-            for (int j = 1; j <= D; j++) t_max = std::max<uint64_t>(t_max, set_n[j]);
-            th.wv = std::max(1, bits_of(t_max));
-            const int key_bits = th.wa + 2 * (th.wv + 1);
-            for (int j = D - 1; j >= 0; j--) {
-                const uint32_t n = set_n[j + 1];
-                if (n == 0) continue;
-                CSV_HIP(ctx, hipMemsetAsync(st->minT, 0xff, (size_t)th.boff[j][n_contigs] * 4, s));
-                launch_st_mint(s, th, j, st->set[j + 1], n, st->node_hash, st->prevrank, st->minT);
-                launch_st_keys(s, th, j, st->set[j + 1], n, st->node_hash, st->prevrank, st->minT, w.k0, w.v0);
-                const int io = launch_radix_sort_u64(s, w.k0, w.v0, w.k1, w.v1, n, key_bits, w.tmp);
-                const uint32_t *sorted = n > 1 ? (io ? w.v1 : w.v0) : w.v0;
-                if (j > 0) launch_st_rank(s, sorted, n, st->prevrank);
-                else launch_st_emit(s, th, sorted, n, st->is_surv, st->node_rec, st->d_out, cap, st->d_count);
-            }
-        }
-        CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, st->d_count, 8, hipMemcpyDeviceToHost, s));
-        CSV_HIP(ctx, wait_stream(s));
-        const uint64_t n_surv = *(const unsigned long long *)ctx->pinned;
         std::vector<csv_split_survivor> &surv = st->surv;
-        surv.resize(n_surv);
-        if (n_surv) {
-            if ((prc = ensure_pinned(ctx, n_surv * sizeof(csv_split_survivor) + 64))) return prc;
-            CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, st->d_out, n_surv * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
+        int prc;
+        if (st->self) {
+            // everything was queued by _begin: the count and the survivors are in (or on their way to) the page-locked block
             CSV_HIP(ctx, wait_stream(s));
-            memcpy(surv.data(), ctx->pinned, n_surv * sizeof(csv_split_survivor));
+            const uint64_t n_surv = *(const unsigned long long *)ctx->pinned;
+            if (n_surv > st->self_bound) { ctx->err = "split_order: more survivors than supplementary records"; return CSV_EHIP; }
+            surv.resize(n_surv);
+            if (n_surv) memcpy(surv.data(), (const char *)ctx->pinned + 64, n_surv * sizeof(csv_split_survivor));
+        } else {
+            const uint64_t n_nodes = st->n_nodes;
+            // (room for one hash per record of these contigs was set aside by _begin; a run's other contigs can add more)
+            struct TmpBuf { void *p = nullptr; ~TmpBuf() { if (p) (void)hipFree(p); } } big_supp;
+            uint64_t *d_supp = st->d_supp;
+            if (n_supp > st->total_reads) {
+                if (hipMalloc(&big_supp.p, n_supp * 8) != hipSuccess) { (void)hipGetLastError(); big_supp.p = nullptr; ctx->err = "hipMalloc failed (supplementary hashes)"; return CSV_ENOMEM; }
+                d_supp = (uint64_t *)big_supp.p;
+            }
+            // (through the context's page-locked block: a pageable copy is staged by the runtime under a lock the lanes' launches also take)
+            prc = ensure_pinned(ctx, std::max<size_t>(n_supp * 8, 4096) + 64);
+            if (prc) return prc;
+            memcpy(ctx->pinned, supp_hash, n_supp * 8);
+            CSV_HIP(ctx, hipMemcpyAsync(d_supp, ctx->pinned, n_supp * 8, hipMemcpyHostToDevice, s));
+            CSV_HIP(ctx, wait_stream(s));                    // (the block is reused for the set sizes below)
+            if ((prc = split_order_tail(ctx, st, d_supp, n_supp, false))) return prc;
+            CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, st->d_count, 8, hipMemcpyDeviceToHost, s));
+            CSV_HIP(ctx, wait_stream(s));
+            const uint64_t n_surv = *(const unsigned long long *)ctx->pinned;
+            if (n_surv > n_nodes) { ctx->err = "split_order: survivor count out of range"; return CSV_EHIP; }
+            surv.resize(n_surv);
+            if (n_surv) {
+                if ((prc = ensure_pinned(ctx, n_surv * sizeof(csv_split_survivor) + 64))) return prc;
+                CSV_HIP(ctx, hipMemcpyAsync(ctx->pinned, st->d_out, n_surv * sizeof(csv_split_survivor), hipMemcpyDeviceToHost, s));
+                CSV_HIP(ctx, wait_stream(s));
+                memcpy(surv.data(), ctx->pinned, n_surv * sizeof(csv_split_survivor));
+            }
         }
         std::sort(surv.begin(), surv.end(), [](const csv_split_survivor &a, const csv_split_survivor &b) { return a.contig != b.contig ? a.contig < b.contig : a.pos < b.pos; });
         for (const csv_split_survivor &v : surv) st->off[v.contig + 1]++;
@@ -1407,6 +1468,11 @@ extern "C" {
 int csvgpu_split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq)
 {
     return split_order_begin(ctx, n_contigs, shards, min_mapq, -1);
+}
+
+int csvgpu_split_order_begin_self(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq)
+{
+    return split_order_begin(ctx, n_contigs, shards, min_mapq, -1, true);
 }
 
 int csvgpu_split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t n_supp, uint32_t *out_rec, uint64_t capacity, uint64_t *out_off)

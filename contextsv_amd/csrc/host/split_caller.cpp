@@ -200,7 +200,9 @@ void SplitPass::Impl::prepare()
     // the device's share starts now: the part of it that needs no supplementary record runs beside the collection below
     std::vector<size_t> dev_contigs;
     for (size_t c = 0; c < contigs.size(); c++) if (on_device(c) && contigs[c].n) dev_contigs.push_back(c);
-    if (!dev_contigs.empty()) params.device_order->begin(dev_contigs, params.min_mapq);
+    size_t n_nonempty = 0;
+    for (const SplitContig &C : contigs) n_nonempty += C.n != 0;
+    if (!dev_contigs.empty()) params.device_order->begin(dev_contigs, params.min_mapq, dev_contigs.size() == n_nonempty);
     std::unique_ptr<csvhost::TraceScope> tr(new csvhost::TraceScope("split: collect"));
     parallel_over(contigs.size(), params.threads, [&](size_t k) {
         const size_t c = by_size[k];

@@ -48,7 +48,10 @@ struct SplitOrderSource {
     virtual void survivors(const std::vector<size_t> &which, int min_mapq, const std::vector<uint64_t> &supp_hash, std::vector<std::vector<uint32_t>> &recs) const = 0;
     // Optional head start: called with the same `which` before the supplementary records have been collected, so that whatever does not
     // depend on them (on the device: the nodes and all but the last epochs of every map, csvgpu_split_order_begin) runs meanwhile.
-    virtual void begin(const std::vector<size_t> &which, int min_mapq) const { (void)which; (void)min_mapq; }
+    // `complete`: `which` holds every contig of the run that has records — every supplementary record of the run is one of theirs, so the
+    // source may take the supplementary hashes from its own copy of the records (csvgpu_split_order_begin_self: nothing then waits for
+    // the collection) and ignore the ones survivors() is given.
+    virtual void begin(const std::vector<size_t> &which, int min_mapq, bool complete) const { (void)which; (void)min_mapq; (void)complete; }
 };
 
 struct SplitParams {

@@ -450,14 +450,18 @@ struct ShardIntervals : IntervalSource {
 // shard of split-pass contig c (its query-name hashes were attached when it was staged)
 struct ShardOrderSource : SplitOrderSource {
     ShardOrderSource(csv_ctx *ctx, std::vector<csv_shard *> shard_of) : ctx(ctx), shard_of(std::move(shard_of)) {}
-    void begin(const std::vector<size_t> &which, int min_mapq) const override
+    void begin(const std::vector<size_t> &which, int min_mapq, bool complete) const override
     {
         pending.clear();
         if (which.empty() || which.size() > 32) return;                           // (more than one batch: the one-call form below)
         { const char *e = getenv("CSV_SPLIT_ONE_CALL"); if (e && *e && *e != '0') return; }      // (A/B: no head start)
         std::vector<csv_shard *> sh(which.size());
         for (size_t k = 0; k < which.size(); k++) sh[k] = shard_of[which[k]];
-        check(ctx, csvgpu_split_order_begin(ctx, (int)sh.size(), sh.data(), (uint8_t)min_mapq), "split-read order (begin)");
+        // every contig of the run in this one call: the supplementary hashes are the shards' own and the whole order is queued now
+        const char *e = getenv("CSV_SPLIT_NO_SELF");                                 // (A/B, tests: wait for the collected hashes)
+        pending_self = complete && !(e && *e && *e != '0');
+        check(ctx, pending_self ? csvgpu_split_order_begin_self(ctx, (int)sh.size(), sh.data(), (uint8_t)min_mapq)
+                                : csvgpu_split_order_begin(ctx, (int)sh.size(), sh.data(), (uint8_t)min_mapq), "split-read order (begin)");
         pending = which; pending_mapq = min_mapq;
     }
     void survivors(const std::vector<size_t> &which, int min_mapq, const std::vector<uint64_t> &supp_hash, std::vector<std::vector<uint32_t>> &recs) const override
@@ -468,10 +472,12 @@ struct ShardOrderSource : SplitOrderSource {
             const size_t nb = which.size();
             std::vector<uint64_t> off(nb + 1, 0);
             std::vector<uint32_t> out(std::max<size_t>(supp_hash.size() * 2, 1024));
-            int rc = csvgpu_split_order_finish(ctx, supp_hash.data(), supp_hash.size(), out.data(), out.size(), off.data());
+            const uint64_t *sh_p = pending_self ? nullptr : supp_hash.data();
+            const uint64_t sh_n = pending_self ? 0 : supp_hash.size();
+            int rc = csvgpu_split_order_finish(ctx, sh_p, sh_n, out.data(), out.size(), off.data());
             if (rc == CSV_ECAPACITY) {
                 out.resize(off[nb]);
-                rc = csvgpu_split_order_finish(ctx, supp_hash.data(), supp_hash.size(), out.data(), out.size(), off.data());
+                rc = csvgpu_split_order_finish(ctx, sh_p, sh_n, out.data(), out.size(), off.data());
             }
             check(ctx, rc, "split-read order");
             for (size_t k = 0; k < nb; k++) recs[k].assign(out.begin() + (std::ptrdiff_t)off[k], out.begin() + (std::ptrdiff_t)off[k + 1]);
@@ -497,6 +503,7 @@ struct ShardOrderSource : SplitOrderSource {
     std::vector<csv_shard *> shard_of;
     mutable std::vector<size_t> pending;          // the contigs csvgpu_split_order_begin was called for, until _finish
     mutable int pending_mapq = 0;
+    mutable bool pending_self = false;            // ... by csvgpu_split_order_begin_self: _finish takes no hashes
 };
 
 }  // namespace

@@ -137,6 +137,15 @@ void launch_exclusive_sum_u32(hipStream_t s, uint32_t *data, uint64_t n, void *t
 }
 
 // ------------------------------------------------------------------------------- radix sort passes
+// keys per wave-tile: small inputs get small tiles so that the pass still fills the chip with waves
+__host__ __device__ static inline int rs_rounds_for(uint64_t n)
+{
+    int rounds = RS_ROUNDS;
+    // fewer keys per tile = more waves but a larger (digit, tile) table to scan: ~128 tiles is the measured sweet spot
+    while (rounds > 2 && (n + (uint64_t)rounds * WAVE - 1) / ((uint64_t)rounds * WAVE) < 128) rounds >>= 1;
+    return rounds;
+}
+
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n, int shift,
                                                             uint32_t *__restrict__ table, uint32_t n_tiles, int rounds)
 {
@@ -194,14 +203,6 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     }
 }
 
-// keys per wave-tile: small inputs get small tiles so that the pass still fills the chip with waves
-static int rs_rounds_for(uint64_t n)
-{
-    int rounds = RS_ROUNDS;
-    // fewer keys per tile = more waves but a larger (digit, tile) table to scan: ~128 tiles is the measured sweet spot
-    while (rounds > 2 && (n + (uint64_t)rounds * WAVE - 1) / ((uint64_t)rounds * WAVE) < 128) rounds >>= 1;
-    return rounds;
-}
 
 // ---- the same passes in ONE launch each ("onesweep": Adinets & Merrill) ---------------------------------------------------------------
 // The three launches of a pass exist to turn per-tile digit counts into global offsets. A digit's base (how many keys have a smaller
@@ -217,10 +218,14 @@ static int rs_rounds_for(uint64_t n)
 constexpr uint32_t OS_AGG = 1u << 30, OS_INC = 2u << 30, OS_VAL = (1u << 30) - 1;
 constexpr int OS_MAX_PASSES = 8;
 constexpr uint32_t OS_SPIN_LIMIT = 1u << 24;
+constexpr int OS_LOOK = 8;
 
-__global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n, int passes, uint32_t *__restrict__ ghist)
+// (n_dev: the key count lives in device memory — a sort queued before the kernel that counts its keys has run; n is then only its bound)
+__global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ n_dev, int passes,
+                                                            uint32_t *__restrict__ ghist)
 {
     __shared__ uint32_t h[OS_MAX_PASSES][RS_BINS];
+    if (n_dev) n = *n_dev;
     for (int p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RS_THREADS) {
@@ -235,10 +240,16 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint64_t *__r
 }
 
 __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t n, int shift,
-                                                            const uint32_t *__restrict__ ghist, uint32_t *status, uint32_t *counter, uint32_t *err,
-                                                            uint32_t n_tiles, int rounds, uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out)
+                                                            const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ ghist, uint32_t *status,
+                                                            uint32_t *counter, uint32_t *err, uint32_t n_tiles, int rounds, uint64_t *__restrict__ keys_out,
+                                                            uint32_t *__restrict__ vals_out)
 {
     static_assert(RS_THREADS == RS_BINS, "one thread per digit");
+    if (n_dev) {                                           // every workgroup derives the same tiling from the same count
+        n = *n_dev;
+        rounds = rs_rounds_for(n);
+        n_tiles = (uint32_t)((n + (uint64_t)rounds * WAVE - 1) / ((uint64_t)rounds * WAVE));
+    }
     __shared__ uint32_t offs[RS_WAVES][RS_BINS];
     __shared__ uint32_t wsum[RS_WAVES];
     __shared__ uint32_t s_tile;
@@ -247,6 +258,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(const uint64_t *__r
     for (int b = lane; b < RS_BINS; b += WAVE) offs[wave][b] = 0;
     __syncthreads();
     const uint32_t wg_tile = s_tile;
+    if ((uint64_t)wg_tile * RS_WAVES >= n_tiles) return;                 // (a grid sized for the bound: nobody looks back at a tile without keys)
     const uint64_t tile = (uint64_t)wg_tile * RS_WAVES + wave;
     const uint64_t t0 = tile * (uint64_t)rounds * WAVE;
     if (tile < n_tiles) {
@@ -270,20 +282,33 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(const uint64_t *__r
         uint32_t base = incl - g;
         for (int w = 0; w < wave; w++) base += wsum[w];
         // keys of this digit in the tiles before this one
+        // (OS_LOOK predecessors per step, their loads in flight together: when every tile of a pass starts at once the walk is as long as
+        // the tile's index, and one dependent global load per predecessor made a 300-tile pass ~250 us)
         uint32_t excl = 0;
         if (wg_tile > 0) {
-            uint32_t j = wg_tile - 1, spins = 0;
-            for (;;) {
-                const uint32_t v = __hip_atomic_load(status + (uint64_t)j * RS_BINS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t f = v >> 30;
-                if (f == 0) {
+            int64_t j = (int64_t)wg_tile - 1;
+            uint32_t spins = 0;
+            bool done = false;
+            while (!done && j >= 0) {
+                uint32_t v[OS_LOOK];
+#pragma unroll
+                for (int k = 0; k < OS_LOOK; k++)
+                    v[k] = j - k >= 0 ? __hip_atomic_load(status + (uint64_t)(j - k) * RS_BINS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_INC;
+                int used = 0;
+#pragma unroll
+                for (int k = 0; k < OS_LOOK; k++) {
+                    if (done || used < k) continue;                   // (stopped at an earlier entry of this batch)
+                    const uint32_t f = v[k] >> 30;
+                    if (f == 0) continue;                              // not published yet: poll again from here
+                    excl += v[k] & OS_VAL;
+                    used = k + 1;
+                    if (f == 2) done = true;
+                }
+                j -= used;
+                if (used == 0) {
                     if (++spins > OS_SPIN_LIMIT) { *err = 1u; break; }
                     __builtin_amdgcn_s_sleep(1);
-                    continue;
                 }
-                excl += v & OS_VAL;
-                if (f == 2 || j == 0) break;
-                j--;
             }
             __hip_atomic_store(st, OS_INC | ((excl + tot) & OS_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -330,6 +355,40 @@ static bool onesweep_on()
     return !(e && *e == '0');
 }
 
+
+// [0, 256): tile counters (one per pass) and the error flag; digit totals of every pass; status words of every pass
+static void launch_onesweep(hipStream_t s, uint64_t *ki, uint32_t *vi, uint64_t *ko, uint32_t *vo, uint64_t n, const uint32_t *n_dev, int passes, unsigned grid,
+                            uint32_t n_tiles, int rounds, void *tmp)
+{
+    uint32_t *counters = (uint32_t *)tmp, *err = counters + OS_MAX_PASSES;
+    uint32_t *ghist = (uint32_t *)((char *)tmp + 256);
+    uint32_t *status = (uint32_t *)((char *)ghist + align_up((size_t)OS_MAX_PASSES * RS_BINS * 4, 256));
+    const size_t used = 256 + align_up((size_t)OS_MAX_PASSES * RS_BINS * 4, 256) + (size_t)passes * grid * RS_BINS * 4;
+    (void)hipMemsetAsync(tmp, 0, used, s);
+    const unsigned hgrid = (unsigned)std::min<uint64_t>((n + 8 * RS_THREADS - 1) / (8 * RS_THREADS), 1024);
+    hipLaunchKernelGGL(os_hist_kernel, dim3(hgrid), dim3(RS_THREADS), 0, s, ki, n, n_dev, passes, ghist);
+    for (int p = 0; p < passes; p++) {
+        hipLaunchKernelGGL(os_pass_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, vi, n, p * RS_BITS, n_dev, ghist + p * RS_BINS, status + (size_t)p * grid * RS_BINS,
+                           counters + p, err, n_tiles, rounds, ko, vo);
+        uint64_t *tk = ki; ki = ko; ko = tk;
+        uint32_t *tv = vi; vi = vo; vo = tv;
+    }
+}
+
+// The same sort for a key count that is still being computed on the device when the sort is queued: n_bound sizes the grid and the
+// workspace (radix_sort_tmp_bytes(n_bound)), *n_dev (<= n_bound, read by the kernels) is the count. Returns where the result ends up
+// (as launch_radix_sort_u64) — the passes always run, also for a count of 0 or 1 — or -1 when n_bound is beyond the look-back's 30-bit counts.
+int launch_radix_sort_u64_devn(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, uint64_t *keys_out, uint32_t *vals_out, uint64_t n_bound,
+                               const uint32_t *n_dev, int key_bits, void *tmp)
+{
+    const int passes = (key_bits + RS_BITS - 1) / RS_BITS;
+    if (n_bound == 0 || passes <= 0) return 0;
+    if (n_bound >= (1ull << 30) || passes > OS_MAX_PASSES) return -1;
+    const unsigned grid = (unsigned)(os_wg_tiles_max(n_bound) - 1);
+    launch_onesweep(s, keys_in, vals_in, keys_out, vals_out, n_bound, n_dev, passes, grid, 0, 0, tmp);
+    return (passes & 1) ? 1 : 0;
+}
+
 size_t radix_sort_tmp_bytes(uint64_t n)
 {
     const uint64_t n_tiles = (n + 2 * WAVE - 1) / (2 * WAVE);         // upper bound (smallest tile)
@@ -352,20 +411,7 @@ int launch_radix_sort_u64(hipStream_t s, uint64_t *keys_in, uint32_t *vals_in, u
     uint64_t *ki = keys_in, *ko = keys_out;
     uint32_t *vi = vals_in, *vo = vals_out;
     if (onesweep_on() && n < (1ull << 30) && passes <= OS_MAX_PASSES && grid + 1 <= os_wg_tiles_max(n)) {
-        // [0, 256): tile counters (one per pass) and the error flag; digit totals of every pass; status words of every pass
-        uint32_t *counters = (uint32_t *)tmp, *err = counters + OS_MAX_PASSES;
-        uint32_t *ghist = (uint32_t *)((char *)tmp + 256);
-        uint32_t *status = (uint32_t *)((char *)ghist + align_up((size_t)OS_MAX_PASSES * RS_BINS * 4, 256));
-        const size_t used = 256 + align_up((size_t)OS_MAX_PASSES * RS_BINS * 4, 256) + (size_t)passes * grid * RS_BINS * 4;
-        (void)hipMemsetAsync(tmp, 0, used, s);
-        const unsigned hgrid = (unsigned)std::min<uint64_t>((n + 8 * RS_THREADS - 1) / (8 * RS_THREADS), 1024);
-        hipLaunchKernelGGL(os_hist_kernel, dim3(hgrid), dim3(RS_THREADS), 0, s, ki, n, passes, ghist);
-        for (int p = 0; p < passes; p++) {
-            hipLaunchKernelGGL(os_pass_kernel, dim3(grid), dim3(RS_THREADS), 0, s, ki, vi, n, p * RS_BITS, ghist + p * RS_BINS, status + (size_t)p * grid * RS_BINS,
-                               counters + p, err, n_tiles, rounds, ko, vo);
-            uint64_t *tk = ki; ki = ko; ko = tk;
-            uint32_t *tv = vi; vi = vo; vo = tv;
-        }
+        launch_onesweep(s, ki, vi, ko, vo, n, nullptr, passes, grid, n_tiles, rounds, tmp);
         return (passes & 1) ? 1 : 0;
     }
     for (int p = 0; p < passes; p++) {

@@ -97,6 +97,29 @@ __global__ __launch_bounds__(SO_THREADS) void so_scatter_kernel(SplitOrderTab ta
     }
 }
 
+// ---- the supplementary records of the same shards: name hashes, in no particular order (the caller sorts them) ----------------------
+// sv_caller.cpp:145-165: a record that passes the same filter and IS supplementary goes to supp_map[qname]; a primary survives the erase
+// (:183-202) when its name has an entry there. When the call holds every contig of the run, the set of those names' hashes is computed
+// here instead of waiting for the caller to collect them.
+__device__ __forceinline__ bool so_pass_supp(uint16_t flag, uint8_t mapq, uint32_t min_mapq)
+{
+    return !(flag & (F_SECONDARY | F_UNMAP | F_DUP | F_QCFAIL)) && (flag & F_SUPP) && mapq >= min_mapq;
+}
+__device__ __forceinline__ uint32_t wave_append(bool p, unsigned int *counter);
+__global__ __launch_bounds__(SO_THREADS) void so_supp_kernel(SplitOrderTab tab, uint32_t min_mapq, uint64_t *__restrict__ supp_hash, unsigned int *__restrict__ count)
+{
+    const uint32_t a = so_owner(tab, blockIdx.x, tab.blk_off);
+    const uint64_t r0 = (uint64_t)(blockIdx.x - tab.blk_off[a]) * SO_BLOCK;
+    const uint64_t n = tab.n_reads[a];
+    for (int k0 = 0; k0 < SO_BLOCK; k0 += SO_THREADS) {
+        const uint64_t r = r0 + k0 + threadIdx.x;
+        const bool p = r < n && so_pass_supp(tab.flag[a][r], tab.mapq[a][r], min_mapq);
+        if (!__ballot(p)) continue;
+        const uint32_t slot = wave_append(p, count);
+        if (p) supp_hash[slot] = tab.qhash[a][r];
+    }
+}
+
 // ---- one epoch ------------------------------------------------------------------------------------------------------------------------
 // Work item j of active contig a enumerates the contig's present nodes in DESCENDING processing time t: the nodes that were in the list
 // when the epoch began sit at t = their list position (list[]), the ones inserted during the epoch at t = their insertion index (which is
@@ -395,48 +418,53 @@ __device__ __forceinline__ uint32_t st_t(const SplitTailTab &tab, int j, uint32_
 {
     return x < tab.F[j][a] ? prevrank[g] : ((1u << tab.wv) | x);
 }
-__global__ __launch_bounds__(SO_THREADS) void st_mint_kernel(SplitTailTab tab, int j, const uint32_t *__restrict__ set, uint32_t n, const uint64_t *__restrict__ node_hash,
-                                                             const uint32_t *__restrict__ prevrank, uint32_t *__restrict__ minT)
+// (n_dev: the set's size is still on the device when the level is queued — csvgpu_split_order_begin_self —; n is then its bound and the
+// launch a fixed grid that strides over the set)
+__global__ __launch_bounds__(SO_THREADS) void st_mint_kernel(SplitTailTab tab, int j, const uint32_t *__restrict__ set, uint32_t n, const uint32_t *__restrict__ n_dev,
+                                                             const uint64_t *__restrict__ node_hash, const uint32_t *__restrict__ prevrank, uint32_t *__restrict__ minT)
 {
-    const uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t g = set[i];
-    const uint32_t a = tail_owner(tab, g);
-    const uint32_t b = tab.boff[j][a] + so_mod(node_hash[g], tab.B[j][a], tab.invB[j][a]);
-    atomicMin(&minT[b], st_t(tab, j, a, g - tab.nbase[a], g, prevrank));
+    if (n_dev) n = *n_dev;
+    for (uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x; i < n; i += gridDim.x * SO_THREADS) {
+        const uint32_t g = set[i];
+        const uint32_t a = tail_owner(tab, g);
+        const uint32_t b = tab.boff[j][a] + so_mod(node_hash[g], tab.B[j][a], tab.invB[j][a]);
+        atomicMin(&minT[b], st_t(tab, j, a, g - tab.nbase[a], g, prevrank));
+    }
 }
-__global__ __launch_bounds__(SO_THREADS) void st_keys_kernel(SplitTailTab tab, int j, const uint32_t *__restrict__ set, uint32_t n, const uint64_t *__restrict__ node_hash,
-                                                             const uint32_t *__restrict__ prevrank, const uint32_t *__restrict__ minT,
+__global__ __launch_bounds__(SO_THREADS) void st_keys_kernel(SplitTailTab tab, int j, const uint32_t *__restrict__ set, uint32_t n, const uint32_t *__restrict__ n_dev,
+                                                             const uint64_t *__restrict__ node_hash, const uint32_t *__restrict__ prevrank, const uint32_t *__restrict__ minT,
                                                              uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
-    const uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t g = set[i];
-    const uint32_t a = tail_owner(tab, g);
-    const uint32_t b = tab.boff[j][a] + so_mod(node_hash[g], tab.B[j][a], tab.invB[j][a]);
-    const uint32_t t = st_t(tab, j, a, g - tab.nbase[a], g, prevrank);
-    const int w = tab.wv + 1;
-    const uint64_t mask = (1ull << w) - 1ull;
-    // ascending in the key = contig ascending, bucket time descending, own time descending: the list order
-    keys[i] = ((uint64_t)a << (2 * w)) | ((~(uint64_t)minT[b] & mask) << w) | (~(uint64_t)t & mask);
-    vals[i] = g;
+    if (n_dev) n = *n_dev;
+    for (uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x; i < n; i += gridDim.x * SO_THREADS) {
+        const uint32_t g = set[i];
+        const uint32_t a = tail_owner(tab, g);
+        const uint32_t b = tab.boff[j][a] + so_mod(node_hash[g], tab.B[j][a], tab.invB[j][a]);
+        const uint32_t t = st_t(tab, j, a, g - tab.nbase[a], g, prevrank);
+        const int w = tab.wv + 1;
+        const uint64_t mask = (1ull << w) - 1ull;
+        // ascending in the key = contig ascending, bucket time descending, own time descending: the list order
+        keys[i] = ((uint64_t)a << (2 * w)) | ((~(uint64_t)minT[b] & mask) << w) | (~(uint64_t)t & mask);
+        vals[i] = g;
+    }
 }
-__global__ __launch_bounds__(SO_THREADS) void st_rank_kernel(const uint32_t *__restrict__ vals, uint32_t n, uint32_t *__restrict__ prevrank)
+__global__ __launch_bounds__(SO_THREADS) void st_rank_kernel(const uint32_t *__restrict__ vals, uint32_t n, const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ prevrank)
 {
-    const uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x;
-    if (i < n) prevrank[vals[i]] = i;
+    if (n_dev) n = *n_dev;
+    for (uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x; i < n; i += gridDim.x * SO_THREADS) prevrank[vals[i]] = i;
 }
 // the survivors of the ordered S_1 with their rank as the position
-__global__ __launch_bounds__(SO_THREADS) void st_emit_kernel(SplitTailTab tab, const uint32_t *__restrict__ vals, uint32_t n, const uint8_t *__restrict__ is_surv,
-                                                             const uint32_t *__restrict__ node_rec, csv_split_survivor *__restrict__ out, uint64_t cap,
-                                                             unsigned long long *__restrict__ count)
+__global__ __launch_bounds__(SO_THREADS) void st_emit_kernel(SplitTailTab tab, const uint32_t *__restrict__ vals, uint32_t n, const uint32_t *__restrict__ n_dev,
+                                                             const uint8_t *__restrict__ is_surv, const uint32_t *__restrict__ node_rec, csv_split_survivor *__restrict__ out,
+                                                             uint64_t cap, unsigned long long *__restrict__ count)
 {
-    const uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t g = vals[i];
-    if (!is_surv[g]) return;
-    const unsigned long long slot = atomicAdd(count, 1ull);
-    if (slot < cap) out[slot] = csv_split_survivor{tail_owner(tab, g), i, node_rec[g]};
+    if (n_dev) n = *n_dev;
+    for (uint32_t i = blockIdx.x * SO_THREADS + threadIdx.x; i < n; i += gridDim.x * SO_THREADS) {
+        const uint32_t g = vals[i];
+        if (!is_surv[g]) continue;
+        const unsigned long long slot = atomicAdd(count, 1ull);
+        if (slot < cap) out[slot] = csv_split_survivor{tail_owner(tab, g), i, node_rec[g]};
+    }
 }
 
 void launch_so_count(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, uint32_t *blk_cnt)
@@ -509,23 +537,29 @@ void launch_st_inverse(hipStream_t s, const SplitTailHost &h, uint32_t n_nodes, 
 {
     if (n_nodes) hipLaunchKernelGGL(st_inverse_kernel, dim3(so_grid(n_nodes)), dim3(SO_THREADS), 0, s, to_tab(h), n_nodes, j_last, list, prevrank);
 }
-void launch_st_mint(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint64_t *node_hash, const uint32_t *prevrank, uint32_t *minT)
+static inline unsigned st_grid(uint32_t n, const uint32_t *n_dev) { return n_dev ? std::min(so_grid(n), 2048u) : so_grid(n); }
+void launch_st_mint(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint32_t *n_dev, const uint64_t *node_hash, const uint32_t *prevrank,
+                    uint32_t *minT)
 {
-    if (n) hipLaunchKernelGGL(st_mint_kernel, dim3(so_grid(n)), dim3(SO_THREADS), 0, s, to_tab(h), j, set, n, node_hash, prevrank, minT);
+    if (n) hipLaunchKernelGGL(st_mint_kernel, dim3(st_grid(n, n_dev)), dim3(SO_THREADS), 0, s, to_tab(h), j, set, n, n_dev, node_hash, prevrank, minT);
 }
-void launch_st_keys(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint64_t *node_hash, const uint32_t *prevrank, const uint32_t *minT,
-                    uint64_t *keys, uint32_t *vals)
+void launch_st_keys(hipStream_t s, const SplitTailHost &h, int j, const uint32_t *set, uint32_t n, const uint32_t *n_dev, const uint64_t *node_hash, const uint32_t *prevrank,
+                    const uint32_t *minT, uint64_t *keys, uint32_t *vals)
 {
-    if (n) hipLaunchKernelGGL(st_keys_kernel, dim3(so_grid(n)), dim3(SO_THREADS), 0, s, to_tab(h), j, set, n, node_hash, prevrank, minT, keys, vals);
+    if (n) hipLaunchKernelGGL(st_keys_kernel, dim3(st_grid(n, n_dev)), dim3(SO_THREADS), 0, s, to_tab(h), j, set, n, n_dev, node_hash, prevrank, minT, keys, vals);
 }
-void launch_st_rank(hipStream_t s, const uint32_t *vals, uint32_t n, uint32_t *prevrank)
+void launch_st_rank(hipStream_t s, const uint32_t *vals, uint32_t n, const uint32_t *n_dev, uint32_t *prevrank)
 {
-    if (n) hipLaunchKernelGGL(st_rank_kernel, dim3(so_grid(n)), dim3(SO_THREADS), 0, s, vals, n, prevrank);
+    if (n) hipLaunchKernelGGL(st_rank_kernel, dim3(st_grid(n, n_dev)), dim3(SO_THREADS), 0, s, vals, n, n_dev, prevrank);
 }
-void launch_st_emit(hipStream_t s, const SplitTailHost &h, const uint32_t *vals, uint32_t n, const uint8_t *is_surv, const uint32_t *node_rec, csv_split_survivor *out,
-                    uint64_t cap, unsigned long long *count)
+void launch_st_emit(hipStream_t s, const SplitTailHost &h, const uint32_t *vals, uint32_t n, const uint32_t *n_dev, const uint8_t *is_surv, const uint32_t *node_rec,
+                    csv_split_survivor *out, uint64_t cap, unsigned long long *count)
 {
-    if (n) hipLaunchKernelGGL(st_emit_kernel, dim3(so_grid(n)), dim3(SO_THREADS), 0, s, to_tab(h), vals, n, is_surv, node_rec, out, cap, count);
+    if (n) hipLaunchKernelGGL(st_emit_kernel, dim3(st_grid(n, n_dev)), dim3(SO_THREADS), 0, s, to_tab(h), vals, n, n_dev, is_surv, node_rec, out, cap, count);
+}
+void launch_so_supp(hipStream_t s, const SplitOrderTab &tab, uint32_t n_blocks, uint32_t min_mapq, uint64_t *supp_hash, unsigned int *count)
+{
+    if (n_blocks) hipLaunchKernelGGL(so_supp_kernel, dim3(n_blocks), dim3(SO_THREADS), 0, s, tab, min_mapq, supp_hash, count);
 }
 
 }  // namespace csv

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSVGPU_ABI_VERSION 2   /* 2: CSV_K_SPLIT_ORDER, csvgpu_split_order_begin / _finish, the job / gate / batch entry points; the test hook left the product library */
+#define CSVGPU_ABI_VERSION 3   /* 3: csvgpu_split_order_begin_self; 2: CSV_K_SPLIT_ORDER, csvgpu_split_order_begin / _finish, the job / gate / batch entry points; the test hook left the product library */
 
 typedef struct csv_ctx csv_ctx;
 
@@ -321,6 +321,11 @@ int csvgpu_split_order(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, ui
  * returns. No other entry point may be called on this context between the two (they share its workspaces); one pending order per context;
  * after CSV_ECAPACITY _finish may be called again with a larger out_rec. */
 int csvgpu_split_order_begin(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq);
+/* _begin for a call that holds EVERY contig of the run (sv_caller.cpp:137-172 fills supp_map from the same records): the supplementary
+ * records' name hashes are then taken from these shards on the device (same filter, flag 0x800 set), and the whole order — nodes, epochs,
+ * survivors — is queued by this call; _finish(ctx, NULL, 0, ...) only waits for it. A caller whose run has supplementary records on contigs
+ * that are not in this call must use _begin and pass all hashes to _finish. */
+int csvgpu_split_order_begin_self(csv_ctx *ctx, int n_contigs, csv_shard *const *shards, uint8_t min_mapq);
 int csvgpu_split_order_finish(csv_ctx *ctx, const uint64_t *supp_hash, uint64_t n_supp, uint32_t *out_rec, uint64_t capacity, uint64_t *out_off);
 
 /* csvgpu_window_log2 on the depth map that the last csvgpu_chr_pipeline_dev() left resident in `shard`

@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/csvgpu.h but not exported"
     assert sorted(_lib.ABI) == names, "ctypes table and header disagree"
-    assert lib.csvgpu_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.csvgpu_abi_version() == _lib.ABI_VERSION == 3
     assert not hasattr(lib, "csvgpu_test_fail_next_alloc"), "the allocation-failure hook must not be in the product library"
 
 

@@ -92,3 +92,49 @@ def test_split_order_argument_checks(ctx):
         assert sorted(got[0].tolist()) == [0, 1]
     finally:
         sh.free()
+
+
+@pytest.mark.parametrize("supp_to", ["same", "any", "none"])
+@pytest.mark.parametrize("sizes", [[0, 1, 2, 13, 14, 59, 60, 541, 542, 2357, 5087, 5088], [10273, 20753, 42044, 85229, 3], [172934, 351061, 400_000]])
+def test_split_order_self_takes_the_supplementary_hashes_from_the_shards(ctx, sizes, supp_to, tail):
+    """csvgpu_split_order_begin_self: the call holds every contig of the run, so the supplementary records' name hashes are the shards' own
+    (flag 0x800 set, same filter as sv_caller.cpp:145) and everything is queued by _begin. Expected = csvgpu_split_order given those hashes
+    (itself checked against the real container above) and, per contig, the real container again. Supplementary records carry the name of a
+    primary on the same contig, on any contig, or of nobody; some fail the mapq / flag filter and must not count."""
+    if supp_to != "same" and len(sizes) != 5:
+        pytest.skip("one size set per extra case")
+    rng = np.random.default_rng(len(sizes) + 7)
+    contigs = [_contig(rng, t, n) for t, n in enumerate(sizes)]
+    hashes = [host.string_hashes(names) if len(names) else np.zeros(0, np.uint64) for _, names in contigs]
+    ok = [((r.flag & (0x100 | 0x4 | 0x400 | 0x200)) == 0) & (r.mapq >= 20) for r, _ in contigs]
+    prim = [np.flatnonzero(o & ((r.flag & 0x800) == 0)) for o, (r, _) in zip(ok, contigs)]
+    all_prim_hashes = np.concatenate([h[p] for h, p in zip(hashes, prim)]) if sizes else np.zeros(0, np.uint64)
+    shards = []
+    try:
+        supp_set = []
+        for t, (reads, names) in enumerate(contigs):
+            h = hashes[t].copy()
+            supp = np.flatnonzero((reads.flag & 0x800) != 0)                      # (also the ones that fail the filter)
+            for i in supp:
+                if supp_to == "none" or rng.random() < 0.2:
+                    h[i] = np.uint64(rng.integers(1, 1 << 62))                    # a name nobody else has
+                elif supp_to == "same" and len(prim[t]):
+                    h[i] = hashes[t][rng.choice(prim[t])]
+                elif len(all_prim_hashes):
+                    h[i] = rng.choice(all_prim_hashes)
+            supp_set.append(h[supp][ok[t][supp]])
+            sh = ctx.upload(reads, 10_000_001)
+            sh.set_qname_hash(h)
+            shards.append(sh)
+        supp_hash = np.unique(np.concatenate(supp_set)) if supp_set else np.zeros(0, np.uint64)
+        exp = ctx.split_order(shards, 20, supp_hash)
+        got = ctx.split_order_self(shards, 20)
+        assert all(np.array_equal(a, b) for a, b in zip(got, exp)), [(len(a), len(b)) for a, b in zip(got, exp)]
+        for t, (reads, names) in enumerate(contigs):
+            keys = [names[i] for i in prim[t]]
+            has = np.isin(hashes[t][prim[t]], supp_hash)
+            order_real, order_emu, buckets = host.umap_order_check(keys, (~has).astype(np.uint8))
+            assert np.array_equal(got[t], prim[t][order_real].astype(np.uint32)), (t, len(names))
+    finally:
+        for sh in shards:
+            sh.free()
