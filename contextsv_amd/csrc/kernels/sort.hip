@@ -261,11 +261,22 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(const uint64_t *__r
     if ((uint64_t)wg_tile * RS_WAVES >= n_tiles) return;                 // (a grid sized for the bound: nobody looks back at a tile without keys)
     const uint64_t tile = (uint64_t)wg_tile * RS_WAVES + wave;
     const uint64_t t0 = tile * (uint64_t)rounds * WAVE;
-    if (tile < n_tiles) {
-        for (int rd = 0; rd < rounds; rd++) {
-            const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
-            if (i < n) atomicAdd(&offs[wave][(uint32_t)(keys_in[i] >> shift) & (RS_BINS - 1)], 1u);
-        }
+    // The wave's whole tile goes into registers with ONE batch of loads: beside the big kernels a global load takes several microseconds,
+    // and a round that waits for its own (twice: count, then scatter) made a 32-round pass ~150 us.
+    uint64_t key[RS_ROUNDS];
+    uint32_t val[RS_ROUNDS];
+    const uint64_t n_here = tile < n_tiles ? n : 0;
+#pragma unroll
+    for (int rd = 0; rd < RS_ROUNDS; rd++) {
+        const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
+        const bool ok = rd < rounds && i < n_here;
+        key[rd] = ok ? keys_in[i] : 0ull;
+        val[rd] = ok ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int rd = 0; rd < RS_ROUNDS; rd++) {
+        const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
+        if (rd < rounds && i < n_here) atomicAdd(&offs[wave][(uint32_t)(key[rd] >> shift) & (RS_BINS - 1)], 1u);
     }
     __syncthreads();
     {
@@ -318,27 +329,27 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(const uint64_t *__r
     __syncthreads();
     if (tile >= n_tiles) return;
     const uint64_t lt = lanemask_lt();
-    for (int rd = 0; rd < rounds; rd++) {
-        const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
-        const bool valid = i < n;
-        uint64_t key = 0; uint32_t val = 0;
-        if (valid) { key = keys_in[i]; val = vals_in[i]; }
-        const uint32_t d = (uint32_t)(key >> shift) & (uint32_t)(RS_BINS - 1);
-        uint64_t mask = __ballot(valid);
-        if (mask == 0) break;
 #pragma unroll
-        for (int b = 0; b < RS_BITS; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            mask &= bit ? bal : ~bal;
+    for (int rd = 0; rd < RS_ROUNDS; rd++) {
+        const uint64_t i = t0 + (uint64_t)rd * WAVE + lane;
+        const bool valid = rd < rounds && i < n;
+        const uint32_t d = (uint32_t)(key[rd] >> shift) & (uint32_t)(RS_BINS - 1);
+        uint64_t mask = __ballot(valid);
+        if (mask != 0) {
+#pragma unroll
+            for (int b = 0; b < RS_BITS; b++) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                mask &= bit ? bal : ~bal;
+            }
+            uint32_t base = 0;
+            if (valid) base = offs[wave][d];
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rank = (uint32_t)__popcll(mask & lt);
+            if (valid && rank == 0) offs[wave][d] = base + (uint32_t)__popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) { keys_out[base + rank] = key[rd]; vals_out[base + rank] = val[rd]; }
         }
-        uint32_t base = 0;
-        if (valid) base = offs[wave][d];
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t rank = (uint32_t)__popcll(mask & lt);
-        if (valid && rank == 0) offs[wave][d] = base + (uint32_t)__popcll(mask);
-        __builtin_amdgcn_wave_barrier();
-        if (valid) { keys_out[base + rank] = key; vals_out[base + rank] = val; }
     }
 }
 
