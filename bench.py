@@ -227,7 +227,7 @@ def main():
 
     def step():
         calls, tid, st, per = genome.run(ctx, hmm, lanes=lane_ctx, eps=args.eps, min_pts_pct=args.min_pts_pct, host_threads=args.host_threads, capacity=cap,
-                                         overlap_split=not args.no_split_overlap)
+                                         overlap_split=not args.no_split_overlap, copy=False)
         gathered = None
         if world > 1:
             per_shard = {int(t): calls[tid == t] for t in np.unique(tid)}
@@ -262,6 +262,7 @@ def main():
         acc = vals if acc is None else [a + b for a, b in zip(acc, vals)]
     barrier()
     elapsed = time.perf_counter() - t0
+    calls, tid = calls.copy(), tid.copy()                                  # (views of the genome's result buffers: the legs below run it again)
     thr1 = cpu_throttle()
     timing = {}
     for c in (lane_ctx or []) + [ctx]:

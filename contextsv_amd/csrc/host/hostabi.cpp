@@ -677,8 +677,8 @@ int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *co
         P.overlap_split_prepare = (passes & 16) == 0;
         std::vector<csv_ctx *> lanes(lane_ctxs, lane_ctxs + (n_lanes > 0 ? n_lanes : 0));
         SVCaller caller(ctx);
-        // the call map of a genome is 3e4 records with strings in them: it is torn down beside whatever the caller does next (the previous
-        // run's is waited for here), not inside this call
+        // the call map of a genome is 3e4 records with strings in them: it is torn down beside whatever the caller does next — the next run,
+        // in a loop of runs: the previous run's teardown is waited for when this run hands over its own map, not before it starts
         static std::mutex teardown_mu;                                          // (runs of different genomes may come from different threads)
         static csvhost::WorkerThreads::Ticket teardown = nullptr;
         auto swap_teardown = [](csvhost::WorkerThreads::Ticket next) {
@@ -686,7 +686,6 @@ int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *co
             { std::lock_guard<std::mutex> l(teardown_mu); prev = teardown; teardown = next; }
             if (prev) csvhost::WorkerThreads::instance().wait(prev);
         };
-        swap_teardown(nullptr);
         auto calls_p = std::make_shared<std::unordered_map<std::string, std::vector<SVCall>>>();
         std::unordered_map<std::string, std::vector<SVCall>> &calls = *calls_p;
         struct Hand {                                                           // (also when runResident throws)
@@ -696,7 +695,11 @@ int csvhost_genome_run(csvhost_genome *g, csv_ctx *ctx, int n_lanes, csv_ctx *co
         } hand{calls_p, swap_teardown};
         std::vector<ChrStats> cs;
         RunStageTimes T;
-        caller.runResident(rc, lanes, chmm_from_pod(hmm), P, calls, &cs, &T);
+        {
+            csvhost::TraceScope tr_run("genome_run: runResident (with its locals' teardown)");
+            caller.runResident(rc, lanes, chmm_from_pod(hmm), P, calls, &cs, &T);
+        }
+        csvhost::TraceScope tr_flat("genome_run: calls -> flat records");
         uint64_t k = 0;
         for (size_t i = 0; i < rc.size(); i++) {
             const std::vector<SVCall> &v = calls[rc[i].name];

@@ -275,12 +275,15 @@ class Genome:
         return {"n_reads": nr.value, "n_cigar": nc.value, "depth_len": dl.value, "global_tid": gt.value, "shard": sh.value}
 
     def run(self, ctx: Context, hmm, lanes=None, eps=0.1, min_pts_pct=0.1, sample_size=20, min_cnv=2000, split_svs=True, cigar_cn=True, merges=True,
-            host_threads=0, capacity: int = 1 << 20, host_split_order: bool = False, overlap_split: bool = True):
-        """-> (calls[CALL_DTYPE], global tid per call, stage_times, per-contig chr_stats list)"""
+            host_threads=0, capacity: int = 1 << 20, host_split_order: bool = False, overlap_split: bool = True, copy: bool = True):
+        """-> (calls[CALL_DTYPE], global tid per call, stage_times, per-contig chr_stats list). copy=False: the two arrays are views of buffers
+        the genome owns (two sets, used alternately) and stay valid until the run after the next one."""
         n = len(self)
         if getattr(self, "_cap", 0) < capacity:              # result buffers live with the genome (tens of megabytes of page faults per call otherwise)
-            self._out, self._tid, self._cap = np.empty(capacity, CALL_DTYPE), np.empty(capacity, np.int32), capacity
-        out, tid = self._out, self._tid
+            self._bufs = [(np.empty(capacity, CALL_DTYPE), np.empty(capacity, np.int32)) for _ in range(2)]
+            self._cap, self._flip = capacity, 0
+        self._flip ^= 1
+        out, tid = self._bufs[self._flip]
         k = C.c_uint64(0)
         st = stage_times()
         cs = (chr_stats * max(n, 1))()
@@ -291,7 +294,9 @@ class Genome:
                                          C.byref(k), C.byref(st), cs))
         if k.value > capacity:
             raise RuntimeError("Genome.run: capacity too small")
-        return out[: k.value].copy(), tid[: k.value].copy(), st, list(cs)[:n]
+        if copy:
+            return out[: k.value].copy(), tid[: k.value].copy(), st, list(cs)[:n]
+        return out[: k.value], tid[: k.value], st, list(cs)[:n]
 
     def free(self):
         if self.h:
