@@ -670,6 +670,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
             SplitSetup *S = split.get();
             split_task = csvhost::WorkerThreads::instance().start([&, S, forced_batches] {
                 const double t0 = now_ms();
+                if (const char *e = getenv("CSV_TEST_PREPARE_DELAY_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e)));      // (tests: a first half that outlasts the pass)
                 try { S->pass->prepare(); } catch (...) { S->err = std::current_exception(); }
                 S->ms_prepare = now_ms() - t0;
                 {   // prepare() outlasted the CIGAR pass (short reads): the run has gone on without waiting and no batch may be taken any more

@@ -138,7 +138,12 @@ def test_early_batches_inside_the_pass_give_the_same_calls(ctx):
         ref, ref_tid, st0, _ = g.run(ctx, hmm)                                     # no lanes: nothing early
         assert len(ref) > 20 and st0.n_cigar_cn_regions > 0 and st0.n_split_calls > 0
         for env, kw in (({}, {}), ({"CSV_EARLY_SMALL_BATCHES": "1"}, {}), ({"CSV_EARLY_CN_WAIT_ALL": "1"}, {}), ({"CSV_NO_EARLY_CN": "1"}, {}),
-                        ({"CSV_NO_EARLY_SPLIT": "1", "CSV_EARLY_SMALL_BATCHES": "1"}, {}), ({}, {"overlap_split": False})):
+                        ({"CSV_NO_EARLY_SPLIT": "1", "CSV_EARLY_SMALL_BATCHES": "1"}, {}), ({}, {"overlap_split": False}),
+                        # the split order in two calls with the caller's supplementary hashes instead of queued whole (csvgpu_split_order_begin_self);
+                        # the three-launch radix passes instead of the onesweep ones; a late split-read first half joined behind the pass
+                        ({"CSV_SPLIT_NO_SELF": "1"}, {}), ({"CSV_SORT_ONESWEEP": "0"}, {}), ({"CSV_NO_LATE_JOIN": "1", "CSV_SPLIT_NO_SELF": "1"}, {}),
+                        # the split-read first half made to outlast the CIGAR pass: joined in front of the split chain / behind the pass
+                        ({"CSV_TEST_PREPARE_DELAY_MS": "40"}, {}), ({"CSV_TEST_PREPARE_DELAY_MS": "40", "CSV_NO_LATE_JOIN": "1"}, {})):
             os.environ.update(env)
             try:
                 for _ in range(2):
