@@ -138,3 +138,34 @@ def test_split_order_self_takes_the_supplementary_hashes_from_the_shards(ctx, si
     finally:
         for sh in shards:
             sh.free()
+
+
+def test_split_order_self_with_more_supplementary_records_than_primaries(ctx):
+    """More supplementary records than nodes (the sort's workspace is sized for the larger of the two), several of them per name."""
+    rng = np.random.default_rng(5)
+    shards, exp_sets = [], []
+    try:
+        for t, n in enumerate([3000, 40, 7000]):
+            flag = rng.choice([0, 16, 0x800, 0x810], n, p=[.05, .05, .45, .45]).astype(np.uint16)
+            mapq = np.full(n, 60, np.uint8)
+            pos = np.sort(rng.integers(0, 1_000_000, n)).astype(np.int32)
+            reads = Reads(pos, flag, mapq, np.arange(n + 1, dtype=np.uint64), np.full(n, (100 << 4), np.uint32))
+            names = ["q%d_%d" % (t, i) for i in range(n)]
+            h = host.string_hashes(names)
+            prim = np.flatnonzero((flag & 0x800) == 0)
+            supp = np.flatnonzero((flag & 0x800) != 0)
+            if len(prim):
+                h[supp] = h[rng.choice(prim[: max(1, len(prim) // 2)], len(supp))]       # every supplementary record carries a primary's name, many share one
+            sh = ctx.upload(reads, 1_000_001)
+            sh.set_qname_hash(h)
+            shards.append(sh)
+            exp_sets.append((h, prim, supp))
+        supp_hash = np.unique(np.concatenate([h[s] for h, _, s in exp_sets]))
+        exp = ctx.split_order(shards, 20, supp_hash)
+        got = ctx.split_order_self(shards, 20)
+        assert all(np.array_equal(a, b) for a, b in zip(got, exp))
+        for (h, prim, _), g in zip(exp_sets, got):
+            assert sorted(g.tolist()) == sorted(prim[np.isin(h[prim], supp_hash)].tolist())
+    finally:
+        for sh in shards:
+            sh.free()
