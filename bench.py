@@ -223,7 +223,8 @@ def main():
     reads_mine = sum(i["reads"] for i in info)
     ops_mine = sum(i["cigar_ops"] for i in info)
     cap = max(1 << 16, 4 * len(mine) * 4096)
-    gather_cap = 1 << 16                                                  # merged calls per rank carried by the final gather (~27 k genome-wide)
+    gather_cap = [1 << 16]                                                # merged calls per rank carried by the final gather: a worst case for the
+                                                                          # warm-up steps, then twice the largest rank's count (set below)
 
     def step():
         calls, tid, st, per = genome.run(ctx, hmm, lanes=lane_ctx, eps=args.eps, min_pts_pct=args.min_pts_pct, host_threads=args.host_threads, capacity=cap,
@@ -233,7 +234,7 @@ def main():
             per_shard = {int(t): calls[tid == t] for t in np.unique(tid)}
             for k in mine:
                 per_shard.setdefault(k, calls[:0])
-            gathered = parallel.gather_calls(per_shard, cap=gather_cap, dist=dist, device=coll_dev)
+            gathered = parallel.gather_calls(per_shard, cap=gather_cap[0], dist=dist, device=coll_dev)
         return calls, tid, st, per, gathered
 
     def barrier():
@@ -245,7 +246,13 @@ def main():
             c.synchronize()
 
     for _ in range(max(args.warmup, 0)):
-        step()
+        warm = step()
+    if world > 1 and args.warmup > 0:
+        # every rank receives world x cap records per step: the capacity follows what the warm-up produced (a step that outgrows it fails loudly)
+        m = torch.tensor([float(len(warm[0]))], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        gather_cap[0] = max(1024, (2 * int(m.item()) + 1023) // 1024 * 1024)
+        step()                                                             # (one more untimed step: the gather's buffers at their final size)
     for c in lane_ctx or [ctx]:
         c.timing_enable(3)                                                 # scan + depth pairs, every launch (contigs differ in size)
         c.timing_reset()

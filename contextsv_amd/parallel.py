@@ -54,21 +54,45 @@ def unpack_calls(buf: np.ndarray) -> dict[int, np.ndarray]:
     return out
 
 
+_gather_bufs: dict = {}            # (cap, world, device) -> page-locked staging + device tensors of the gather (kept between steps)
+
+
 def gather_calls(per_shard: dict[int, np.ndarray], cap: int, dist=None, device=None) -> dict[int, np.ndarray] | None:
     """Final gather: every rank contributes its shards' merged calls; rank 0 gets {shard id: calls} for
-    all shards (other ranks get None). One all_gather of a fixed-size buffer (latency-bound: ~1 MB genome-wide)."""
+    all shards (other ranks get None). One all_gather of a fixed-size buffer of `cap` records per rank (latency-bound: a genome's
+    merged calls are ~1.4 MB in all) — size `cap` from the counts of a warm-up step, not from a worst case: every rank receives
+    world x cap records and rank 0 copies them to the host. On a GPU the buffers are staged through page-locked memory kept between calls."""
     import torch
     buf = pack_calls(per_shard, cap)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return unpack_calls(buf)
-    t = torch.from_numpy(buf)
-    if device is not None:
-        t = t.to(device)
-    out = torch.empty(dist.get_world_size() * t.numel(), dtype=torch.int32, device=t.device)
-    dist.all_gather_into_tensor(out, t)
-    if dist.get_rank() != 0:
-        return None
-    host = out.cpu().numpy().reshape(dist.get_world_size(), -1)
+    world = dist.get_world_size()
+    if device is not None and torch.device(device).type == "cuda":
+        key = (cap, world, str(device))
+        st = _gather_bufs.get(key)
+        if st is None:
+            st = {"send_h": torch.empty(len(buf), dtype=torch.int32).pin_memory(),
+                  "send_d": torch.empty(len(buf), dtype=torch.int32, device=device),
+                  "recv_d": torch.empty(world * len(buf), dtype=torch.int32, device=device),
+                  "recv_h": torch.empty(world * len(buf), dtype=torch.int32).pin_memory() if dist.get_rank() == 0 else None}
+            _gather_bufs.clear()                       # (one size at a time: a new capacity replaces the old buffers)
+            _gather_bufs[key] = st
+        st["send_h"].numpy()[:] = buf
+        st["send_d"].copy_(st["send_h"], non_blocking=True)
+        dist.all_gather_into_tensor(st["recv_d"], st["send_d"])
+        if dist.get_rank() == 0:
+            st["recv_h"].copy_(st["recv_d"], non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()       # (every rank: the staging buffers are reused by the next call)
+        if dist.get_rank() != 0:
+            return None
+        host = st["recv_h"].numpy().reshape(world, -1)
+    else:
+        t = torch.from_numpy(buf)
+        out = torch.empty(world * t.numel(), dtype=torch.int32)
+        dist.all_gather_into_tensor(out, t)
+        if dist.get_rank() != 0:
+            return None
+        host = out.numpy().reshape(world, -1)
     merged = {}
     for r in range(host.shape[0]):
         merged.update(unpack_calls(host[r]))
