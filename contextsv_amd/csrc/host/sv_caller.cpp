@@ -360,6 +360,7 @@ void SVCaller::processResidentChromosomesPipelined(const std::vector<csv_shard *
             st.depth_sum = res.depth_sum; st.depth_nonzero = res.depth_nonzero; st.mean_chr_cov = res.mean_cov; st.dbscan_min_pts = res.min_pts;
             out.n_del = res.n_del; out.n_ins = res.n_ins;
             st.ms_device = now_ms() - t0;
+            if (on_device) on_device(i);
             { std::lock_guard<std::mutex> l(mu); ready[i] = 1; }
             cv.notify_all();
         }
@@ -392,7 +393,8 @@ std::vector<int> SVCaller::assignShards(const std::vector<double> &weights, int 
 
 void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double eps, double pct,
                                     std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats,
-                                    const std::function<void(size_t lane, size_t k)> &on_merged, int min_mapq, int min_oplen)
+                                    const std::function<void(size_t lane, size_t k)> &on_merged, int min_mapq, int min_oplen,
+                                    const std::function<void(size_t lane, size_t k)> &on_device)
 {
     calls.assign(lanes.size(), {});
     stats.assign(lanes.size(), {});
@@ -405,6 +407,7 @@ void SVCaller::processResidentLanes(const std::vector<Lane> &lanes, const SeqSto
                 SVCaller caller(lanes[l].ctx);
                 caller.min_mapq = min_mapq; caller.min_oplen = min_oplen;
                 if (on_merged) caller.on_merged = [&on_merged, l](size_t k) { on_merged(l, k); };
+                if (on_device) caller.on_device = [&on_device, l](size_t k) { on_device(l, k); };
                 if (!lanes[l].seqs.empty()) caller.processResidentChromosomesPipelined(lanes[l].shards, lanes[l].seqs, eps, pct, calls[l], stats[l]);
                 else caller.processResidentChromosomesPipelined(lanes[l].shards, seq, eps, pct, calls[l], stats[l]);
             } catch (...) { errs[l] = std::current_exception(); }
@@ -655,6 +658,14 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         size_t regions = 0;
         bool pass_over = false;                            // (under mu) the CIGAR pass has returned: the task stops taking batches
         bool prepare_over = false;                         // (under mu) the task is past prepare()
+        // A rank with few contigs (or short reads: a first half as long as the pass) takes no batch of the kind above. Its split chain needs the
+        // scans' alignment intervals and, for its copy-number pass, the depth maps and mean coverages — all there when the contigs' device chains
+        // are over, before their host merges: the task runs it for ALL contigs then, beside the rest of the pass and the CIGAR copy-number pass.
+        size_t device_done = 0;                            // (under mu) contigs whose device chain is over
+        bool split_only = false;                           // (under mu) the task has decided to do that; the run meets it in front of the split chain
+        bool main_joins_later = false;                     // (under mu, set with pass_over) the run has gone on without waiting for the task
+        bool pre_ready = false;                            // pre_split holds every contig's split-read calls (read after the join)
+        std::unordered_map<std::string, std::vector<SVCall>> pre_split;
     } early;
     early.done.assign(n, 0);
     early.finished.assign(n, 0);
@@ -673,12 +684,60 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                 if (const char *e = getenv("CSV_TEST_PREPARE_DELAY_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e)));      // (tests: a first half that outlasts the pass)
                 try { S->pass->prepare(); } catch (...) { S->err = std::current_exception(); }
                 S->ms_prepare = now_ms() - t0;
-                {   // prepare() outlasted the CIGAR pass (short reads): the run has gone on without waiting and no batch may be taken any more
-                    std::lock_guard<std::mutex> l(early.mu);
+                if (S->err) { std::lock_guard<std::mutex> l(early.mu); early.prepare_over = true; return; }
+                // the split chain + its copy-number pass for every contig, on this thread and the caller's context (see EarlyCn::split_only)
+                auto split_only_batch = [&] {
+                    try {
+                        for (;;) {
+                            { std::lock_guard<std::mutex> l(early.mu); if (early.device_done >= n_lane_contigs || early.pass_over) break; }
+                            std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        }
+                        csvhost::TraceScope tr("run: split chain beside the pass");
+                        static const EmptySnps no_snps;
+                        csvhost::set_thread_context(ctx);
+                        std::vector<size_t> blocks;
+                        std::unordered_map<std::string, std::pair<size_t, size_t>> lane_of;
+                        for (size_t l = 0; l < L; l++)
+                            for (size_t k = 0; k < which[l].size(); k++) {
+                                const int b = S->block_of[which[l][k]];
+                                if (b >= 0) blocks.push_back((size_t)b);
+                                lane_of[contigs[which[l][k]].name] = std::make_pair(l, k);
+                            }
+                        S->pass->finishFor(blocks, early.pre_split);
+                        std::vector<CNVCaller::ContigJob> sj;
+                        for (auto &entry : early.pre_split) {
+                            if (entry.second.empty()) continue;
+                            const auto lk = lane_of.at(entry.first);
+                            const size_t i = which[lk.first][lk.second];
+                            CNVCaller::ContigJob j;
+                            j.chr = entry.first; j.calls = &entry.second; j.mean_chr_cov = lane_stats[lk.first][lk.second].mean_chr_cov; j.shard = contigs[i].shard;
+                            j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
+                            sj.push_back(j);
+                        }
+                        CNVCaller cn(ctx);
+                        cn.sample_size = P.sample_size; cn.min_cnv_length = P.min_cnv_length; cn.host_threads = P.host_threads;
+                        cn.runSplitReadCopyNumberPredictionsAll(sj, hmm);
+                        early.pre_ready = true;
+                        csvhost::set_thread_context(nullptr);
+                    } catch (...) { early.err = std::current_exception(); csvhost::set_thread_context(nullptr); }
+                };
+                const bool can_split_only = !P.save_cnv && !forced_batches && !env_on("CSV_NO_SPLIT_BESIDE_PASS");
+                {   // prepare() outlasted the CIGAR pass (short reads): the run has gone on without waiting and no batch of the first kind may be taken any more
+                    std::unique_lock<std::mutex> l(early.mu);
                     early.prepare_over = true;
-                    if (early.pass_over && !forced_batches) return;
+                    if (early.pass_over && !forced_batches) {
+                        const bool go = early.main_joins_later && can_split_only;
+                        l.unlock();
+                        if (go) split_only_batch();
+                        return;
+                    }
                 }
-                if (!early_cn || S->err) return;
+                if (!early_cn) {
+                    bool go = false;
+                    { std::lock_guard<std::mutex> l(early.mu); if (can_split_only && !early.pass_over) { early.split_only = true; go = true; } }
+                    if (go) split_only_batch();
+                    return;
+                }
                 try {
                     if (env_on("CSV_EARLY_CN_WAIT_ALL")) {                      // tests: every contig through this path, whatever the timing
                         for (int spin = 0; spin < 200000; spin++) {
@@ -701,7 +760,14 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                         // contigs never takes one)
                         // (CSV_EARLY_SMALL_BATCHES: tests — a batch whenever three more contigs are merged, down to the last one)
                         const bool small_batches = env_on("CSV_EARLY_SMALL_BATCHES");
-                        if (unmerged < 8 && !env_on("CSV_EARLY_CN_WAIT_ALL") && !small_batches) break;
+                        if (unmerged < 8 && !env_on("CSV_EARLY_CN_WAIT_ALL") && !small_batches) {
+                            if (taken == 0 && can_split_only) {                         // no batch of this kind at all: the split chain alone, for every contig
+                                bool go = false;
+                                { std::lock_guard<std::mutex> l(early.mu); if (!early.pass_over) { early.split_only = true; go = true; } }
+                                if (go) split_only_batch();
+                            }
+                            break;
+                        }
                         if (small_batches && first && snap.size() < 3 && !over) { std::this_thread::sleep_for(std::chrono::microseconds(100)); continue; }
                         if (!first && (over || snap.size() < 3)) {
                             if (over) break;
@@ -799,13 +865,17 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         } else {
             std::function<void(size_t, size_t)> note;
             if (early_cn) note = [&early](size_t l, size_t k) { std::lock_guard<std::mutex> g(early.mu); early.merged.emplace_back(l, k); };
-            processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats, note, min_mapq, min_oplen);
+            std::function<void(size_t, size_t)> dev_note;
+            if (split_task) dev_note = [&early](size_t, size_t) { std::lock_guard<std::mutex> g(early.mu); early.device_done++; };
+            processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats, note, min_mapq, min_oplen, dev_note);
         }
         T.ms_cigar = now_ms() - t_begin;
         // (the early copy-number batch works on lane_calls in place: it must be over before they move. A task still inside prepare()
         // takes no batch after the pass: the run goes on — the CIGAR copy-number pass needs nothing of prepare() — and meets the task in
         // front of the split chain.)
-        { std::lock_guard<std::mutex> l(early.mu); early.pass_over = true; join_later = split_task && !early.prepare_over && !forced_batches && !env_on("CSV_NO_LATE_JOIN"); }
+        { std::lock_guard<std::mutex> l(early.mu); early.pass_over = true;
+          join_later = split_task && (!early.prepare_over || early.split_only) && !forced_batches && !env_on("CSV_NO_LATE_JOIN");
+          early.main_joins_later = join_later; }
         if (split_task && !join_later) { csvhost::WorkerThreads::instance().wait(split_task); split_task = nullptr; }
         for (size_t l = 0; l < L; l++)
             for (size_t k = 0; k < which[l].size(); k++) { per[which[l][k]] = std::move(lane_calls[l][k]); stats[which[l][k]] = lane_stats[l][k]; }
@@ -823,7 +893,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
     T.n_cigar_cn_regions += early.regions;                                  // (a task joined later has taken no batch)
     T.n_split_calls += early.n_split_calls;
     finishRun(contigs, stats, hmm, P, whole_genome_sv_calls, T, split.get(), lane_ctxs.size() > 1 ? lane_ctxs[0] : nullptr, early_cn ? &early.done : nullptr,
-              early_cn ? &early.finished : nullptr, join_later ? &join : nullptr);
+              early_cn ? &early.finished : nullptr, join_later ? &join : nullptr, &early.pre_split, &early.pre_ready);
     T.ms_total = now_ms() - t_begin;
     if (stats_out) *stats_out = stats;
     if (times) *times = T;
@@ -855,7 +925,8 @@ std::unique_ptr<SVCaller::SplitSetup> SVCaller::makeSplitSetup(std::vector<Resid
 
 void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector<ChrStats> &stats, const CHMM &hmm, const RunParams &P,
                          std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split, csv_ctx *side_ctx,
-                         const std::vector<char> *cigar_cn_done, const std::vector<char> *finished, const std::function<void()> *before_split)
+                         const std::vector<char> *cigar_cn_done, const std::vector<char> *finished, const std::function<void()> *before_split,
+                         std::unordered_map<std::string, std::vector<SVCall>> *pre_split, const bool *pre_split_ready)
 {
     const EmptySnps no_snps;
     csvhost::WorkerThreads::Ticket teardown = nullptr;
@@ -926,7 +997,9 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         T.ms_split_fetch = 0.0;
         std::unordered_map<std::string, std::vector<SVCall>> split_calls;
         if (before_split) (*before_split)();                                       // (prepare() still running on its thread: meet it here)
-        split->pass->finish(split_calls);                                          // (runs prepare() first when nobody has)
+        const bool pre = pre_split && pre_split_ready && *pre_split_ready;         // (the split chain and its copy-number pass ran beside the CIGAR pass)
+        if (pre) split_calls = std::move(*pre_split);
+        else split->pass->finish(split_calls);                                     // (runs prepare() first when nobody has)
         T.ms_split_prepare = split->ms_prepare;
         {   // the pass's working set (1e5 small vectors for a genome) is torn down beside the next stages, not between them
             std::shared_ptr<SplitPass> dead(split->pass.release());
@@ -934,7 +1007,7 @@ void SVCaller::finishRun(std::vector<ResidentContig> &contigs, const std::vector
         }
         T.ms_split = now_ms() - t0;
         t0 = now_ms();
-        {
+        if (!pre) {
             std::vector<CNVCaller::ContigJob> jobs = cn_jobs(split_calls);
             cnv.runSplitReadCopyNumberPredictionsAll(jobs, hmm);
         }

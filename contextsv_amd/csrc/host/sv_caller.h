@@ -144,9 +144,13 @@ public:
 
     static void processResidentLanes(const std::vector<Lane> &lanes, const SeqStore *seq, double dbscan_epsilon, double dbscan_min_pts_pct,
                                      std::vector<std::vector<std::vector<SVCall>>> &calls, std::vector<std::vector<ChrStats>> &stats,
-                                     const std::function<void(size_t lane, size_t k)> &on_merged = {}, int min_mapq = 20, int min_oplen = 50);
+                                     const std::function<void(size_t lane, size_t k)> &on_merged = {}, int min_mapq = 20, int min_oplen = 50,
+                                     const std::function<void(size_t lane, size_t k)> &on_device = {});
     // called by processResidentChromosomesPipelined's merge threads when shard i's calls and statistics are final (any thread; may be empty)
     std::function<void(size_t)> on_merged;
+    // called by processResidentChromosomesPipelined when shard i's device chain is over — depth map, alignment intervals and its statistics
+    // (mean coverage) are final, its calls not yet: the host merge follows (the calling thread; may be empty)
+    std::function<void(size_t)> on_device;
 
     // Pass ordering of SVCaller::run (sv_caller.cpp:747-946) over in-memory contigs: depth + CIGAR pass + CIGAR merge per
     // contig -> CIGAR copy-number predictions -> split-read signatures -> their copy-number predictions ->
@@ -189,7 +193,9 @@ private:
                    std::unordered_map<std::string, std::vector<SVCall>> &whole_genome_sv_calls, RunStageTimes &T, SplitSetup *split = nullptr,
                    csv_ctx *side_ctx = nullptr, const std::vector<char> *cigar_cn_done = nullptr /* per contig: CIGAR copy-number predictions already made */,
                    const std::vector<char> *finished = nullptr /* per contig: every stage already made (its entry of the call map is final) */,
-                   const std::function<void()> *before_split = nullptr /* called in front of the split chain: joins a prepare() still running */);
+                   const std::function<void()> *before_split = nullptr /* called in front of the split chain: joins a prepare() still running */,
+                   std::unordered_map<std::string, std::vector<SVCall>> *pre_split = nullptr, const bool *pre_split_ready = nullptr
+                   /* (read after before_split) the split-read calls of every contig, copy-number predictions made: the chain ran beside the CIGAR pass */);
     struct DeviceOut {                       // what the device chain of one shard hands to the host merge: page-locked result buffers
         csv_ctx *ctx = nullptr;
         csv_sig *sig = nullptr;

@@ -143,7 +143,10 @@ def test_early_batches_inside_the_pass_give_the_same_calls(ctx):
                         # the three-launch radix passes instead of the onesweep ones; a late split-read first half joined behind the pass
                         ({"CSV_SPLIT_NO_SELF": "1"}, {}), ({"CSV_SORT_ONESWEEP": "0"}, {}), ({"CSV_NO_LATE_JOIN": "1", "CSV_SPLIT_NO_SELF": "1"}, {}),
                         # the split-read first half made to outlast the CIGAR pass: joined in front of the split chain / behind the pass
-                        ({"CSV_TEST_PREPARE_DELAY_MS": "40"}, {}), ({"CSV_TEST_PREPARE_DELAY_MS": "40", "CSV_NO_LATE_JOIN": "1"}, {})):
+                        ({"CSV_TEST_PREPARE_DELAY_MS": "40"}, {}), ({"CSV_TEST_PREPARE_DELAY_MS": "40", "CSV_NO_LATE_JOIN": "1"}, {}),
+                        # without / with the split chain of all contigs beside the pass (what a run that takes no early batch does by default)
+                        ({"CSV_NO_SPLIT_BESIDE_PASS": "1"}, {}), ({"CSV_NO_SPLIT_BESIDE_PASS": "1", "CSV_TEST_PREPARE_DELAY_MS": "40"}, {}),
+                        ({"CSV_NO_EARLY_CN": "1", "CSV_NO_SPLIT_BESIDE_PASS": "1"}, {})):
             os.environ.update(env)
             try:
                 for _ in range(2):
