@@ -120,7 +120,27 @@ int csvhost_sort_select_check(const uint32_t *keys, uint64_t n, uint64_t nth, in
         auto cmp = [&](uint32_t x, uint32_t y) { return keys[x] > keys[y]; };
         std::sort(a.begin(), a.end(), cmp);
         *id_std = a[nth];
-        *id_sel = *csvhost::std_sort_select(b.begin(), b.end(), (std::ptrdiff_t)nth, cmp);
+        *id_sel = *csvhost::std_sort_select(b.data(), b.data() + n, (std::ptrdiff_t)nth, cmp);       // (pointers: the block-wise partition for large ranges)
+    })
+}
+
+// test hook: one partition step of sort_select.h on ids sorted descending by key — the library's loop and the block-wise form must leave
+// the same cut and the same arrangement. *differ = 0 when they agree (ranges of more than 16, as in std::sort: the unguarded loops need the
+// median-of-three's sentinels).
+int csvhost_partition_check(const uint32_t *keys, uint64_t n, int *differ)
+{
+    GUARD({
+        std::vector<uint32_t> a(n), b(n);
+        for (uint64_t i = 0; i < n; i++) a[i] = b[i] = (uint32_t)i;
+        auto cmp = [&](uint32_t x, uint32_t y) { return keys[x] > keys[y]; };
+        *differ = 0;
+        if (n > 16) {
+            csvhost::lib_move_median_to_first(a.data(), a.data() + 1, a.data() + n / 2, a.data() + n - 1, cmp);
+            csvhost::lib_move_median_to_first(b.data(), b.data() + 1, b.data() + n / 2, b.data() + n - 1, cmp);
+            uint32_t *ca = csvhost::lib_unguarded_partition(a.data() + 1, a.data() + n, a.data(), cmp);
+            uint32_t *cb = csvhost::lib_unguarded_partition_blocks(b.data() + 1, b.data() + n, b.data(), cmp);
+            *differ = (ca - a.data() != cb - b.data()) || a != b;
+        }
     })
 }
 

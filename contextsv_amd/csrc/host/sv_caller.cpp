@@ -183,6 +183,7 @@ void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t 
         std::vector<std::vector<SVCall>> part;       // per bucket item, in slot order
     } W[2];
     constexpr size_t kChunks = 8;
+    std::unique_ptr<csvhost::TraceScope> tr(new csvhost::TraceScope("merge: label counts + scatter"));
     for (int t = 0; t < 2; t++) { W[t].base = t ? n_del : 0; W[t].n = big[t] ? type_n[t] : 0; W[t].cnt.assign(kChunks, {}); W[t].member.resize(W[t].n); }
     auto chunk = [&](const TypeWork &w, size_t c, uint64_t &a, uint64_t &b) { a = w.n * c / kChunks; b = w.n * (c + 1) / kChunks; };
     csvhost::parallel_for(2 * kChunks, 0, [&](size_t it) {
@@ -214,6 +215,7 @@ void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t 
     });
     // bucket items per type: [0, 1) = the noise bucket, then the clusters in kRanges ranges
     constexpr size_t kRanges = 7;
+    tr.reset(new csvhost::TraceScope("merge: buckets (noise bucket + cluster ranges)"));
     for (int t = 0; t < 2; t++) W[t].part.assign(1 + kRanges, {});
     csvhost::parallel_for(2 * (1 + kRanges), 0, [&](size_t it) {
         TypeWork &w = W[it / (1 + kRanges)];
@@ -238,6 +240,7 @@ void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t 
             dst.push_back(std::move(rep));
         }
     });
+    tr.reset();
     for (int t = 0; t < 2; t++)
         for (auto &v : W[t].part) chr_sv_calls.insert(chr_sv_calls.end(), std::make_move_iterator(v.begin()), std::make_move_iterator(v.end()));
 }
@@ -245,6 +248,7 @@ void SVCaller::mergeOrdered(const csv_sig *sig, const int32_t *labels, uint64_t 
 void SVCaller::hostMerge(const std::string &chr, const DeviceOut &in, const SeqStore *seq, std::vector<SVCall> &chr_sv_calls, ChrStats &st, bool share_pool)
 {
     const double t1 = now_ms();
+    csvhost::TraceScope tr("lane: host merge");
     printMessage(chr + ": Merging CIGAR...");
     mergeOrdered(in.sig, in.lab, in.n_del, in.n_ins, seq, chr_sv_calls, share_pool);
     st.ms_host_merge = now_ms() - t1;

@@ -69,6 +69,7 @@ def load() -> C.CDLL:
                                 C.c_int, C.c_uint32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), _P, C.c_char_p, C.c_char_p, C.c_char_p, _P, C.c_uint64, _P, C.c_int]
     lib.csvhost_read_chmm.argtypes = [C.c_char_p, C.POINTER(_lib.csv_hmm), C.POINTER(C.c_int32)]
     lib.csvhost_sort_select_check.argtypes = [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.csvhost_partition_check.argtypes = [_P, C.c_uint64, C.POINTER(C.c_int)]
     lib.csvhost_fasta_open.restype = _P
     lib.csvhost_fasta_open.argtypes = [C.c_char_p]
     lib.csvhost_fasta_free.argtypes = [_P]
@@ -497,6 +498,14 @@ def sort_select_check(keys: np.ndarray, nth: int):
     a, b = C.c_int64(-1), C.c_int64(-1)
     _check(load().csvhost_sort_select_check(keys.ctypes.data, len(keys), nth, C.byref(a), C.byref(b)))
     return a.value, b.value
+
+
+def partition_check(keys: np.ndarray) -> bool:
+    """One partition step of sort_select.h: True when the block-wise form leaves the cut and the arrangement of the library's loop."""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    d = C.c_int(1)
+    _check(load().csvhost_partition_check(keys.ctypes.data, len(keys), C.byref(d)))
+    return d.value == 0
 
 
 def read_chmm(path: str):

@@ -35,3 +35,13 @@ def test_select_large_noise_bucket_slot():
         top = max(1, int(n * 0.2))
         a, b = host.sort_select_check(keys, top // 2)
         assert a == b
+
+
+@pytest.mark.parametrize("n", [17, 64, 65, 127, 128, 129, 191, 192, 193, 257, 1000, 1025, 4097, 20_000])
+def test_block_partition_equals_the_library_loop(n):
+    """The branch-free block-wise partition (large ranges) makes the same swaps as libstdc++'s __unguarded_partition: same cut, same arrangement."""
+    rng = np.random.default_rng(n + 1)
+    for name, keys in _patterns(rng, n):
+        assert host.partition_check(np.ascontiguousarray(keys, np.uint32)), (name, n)
+    for _ in range(20):
+        assert host.partition_check(rng.integers(0, int(rng.integers(1, 50)), n).astype(np.uint32))
