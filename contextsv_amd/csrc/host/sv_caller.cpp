@@ -665,7 +665,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
         // A rank with few contigs (or short reads: a first half as long as the pass) takes no batch of the kind above. Its split chain needs the
         // scans' alignment intervals and, for its copy-number pass, the depth maps and mean coverages — all there when the contigs' device chains
         // are over, before their host merges: the task runs it for ALL contigs then, beside the rest of the pass and the CIGAR copy-number pass.
-        size_t device_done = 0;                            // (under mu) contigs whose device chain is over
+        std::vector<std::pair<size_t, size_t>> device_done; // (under mu) (lane, k) of the contigs whose device chain is over, in that order
         bool split_only = false;                           // (under mu) the task has decided to do that; the run meets it in front of the split chain
         bool main_joins_later = false;                     // (under mu, set with pass_over) the run has gone on without waiting for the task
         bool pre_ready = false;                            // pre_split holds every contig's split-read calls (read after the join)
@@ -692,37 +692,48 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                 // the split chain + its copy-number pass for every contig, on this thread and the caller's context (see EarlyCn::split_only)
                 auto split_only_batch = [&] {
                     try {
-                        for (;;) {
-                            { std::lock_guard<std::mutex> l(early.mu); if (early.device_done >= n_lane_contigs || early.pass_over) break; }
-                            std::this_thread::sleep_for(std::chrono::microseconds(50));
-                        }
-                        csvhost::TraceScope tr("run: split chain beside the pass");
                         static const EmptySnps no_snps;
-                        csvhost::set_thread_context(ctx);
-                        std::vector<size_t> blocks;
-                        std::unordered_map<std::string, std::pair<size_t, size_t>> lane_of;
-                        for (size_t l = 0; l < L; l++)
-                            for (size_t k = 0; k < which[l].size(); k++) {
-                                const int b = S->block_of[which[l][k]];
-                                if (b >= 0) blocks.push_back((size_t)b);
-                                lane_of[contigs[which[l][k]].name] = std::make_pair(l, k);
+                        // whatever is ready goes now, the rest as it comes (a rank of six contigs has two ready when the first half is over and
+                        // the last one when the pass ends: what runs behind the pass is that one's chain, not all six)
+                        size_t taken_b = 0;
+                        for (;;) {
+                            std::vector<std::pair<size_t, size_t>> snap;
+                            bool over;
+                            { std::lock_guard<std::mutex> l(early.mu); snap.assign(early.device_done.begin() + (std::ptrdiff_t)taken_b, early.device_done.end()); over = early.pass_over; }
+                            if (snap.empty()) {
+                                if (taken_b >= n_lane_contigs || over) break;          // (over with contigs missing: the pass failed)
+                                std::this_thread::sleep_for(std::chrono::microseconds(50));
+                                continue;
                             }
-                        S->pass->finishFor(blocks, early.pre_split);
-                        std::vector<CNVCaller::ContigJob> sj;
-                        for (auto &entry : early.pre_split) {
-                            if (entry.second.empty()) continue;
-                            const auto lk = lane_of.at(entry.first);
-                            const size_t i = which[lk.first][lk.second];
-                            CNVCaller::ContigJob j;
-                            j.chr = entry.first; j.calls = &entry.second; j.mean_chr_cov = lane_stats[lk.first][lk.second].mean_chr_cov; j.shard = contigs[i].shard;
-                            j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
-                            sj.push_back(j);
+                            taken_b += snap.size();
+                            csvhost::TraceScope tr("run: split chain beside the pass");
+                            csvhost::set_thread_context(ctx);
+                            std::vector<size_t> blocks;
+                            std::unordered_map<std::string, std::pair<size_t, size_t>> lane_of;
+                            for (const auto &lk : snap) {
+                                const int b = S->block_of[which[lk.first][lk.second]];
+                                if (b >= 0) blocks.push_back((size_t)b);
+                                lane_of[contigs[which[lk.first][lk.second]].name] = lk;
+                            }
+                            std::unordered_map<std::string, std::vector<SVCall>> part;
+                            S->pass->finishFor(blocks, part);
+                            std::vector<CNVCaller::ContigJob> sj;
+                            for (auto &entry : part) {
+                                if (entry.second.empty()) continue;
+                                const auto lk = lane_of.at(entry.first);
+                                const size_t i = which[lk.first][lk.second];
+                                CNVCaller::ContigJob j;
+                                j.chr = entry.first; j.calls = &entry.second; j.mean_chr_cov = lane_stats[lk.first][lk.second].mean_chr_cov; j.shard = contigs[i].shard;
+                                j.snps = contigs[i].snps ? contigs[i].snps : (const SNPSource *)&no_snps; j.depth_len = contigs[i].depth_len;
+                                sj.push_back(j);
+                            }
+                            CNVCaller cn(ctx);
+                            cn.sample_size = P.sample_size; cn.min_cnv_length = P.min_cnv_length; cn.host_threads = P.host_threads;
+                            cn.runSplitReadCopyNumberPredictionsAll(sj, hmm);
+                            for (auto &entry : part) early.pre_split[entry.first] = std::move(entry.second);
+                            csvhost::set_thread_context(nullptr);
                         }
-                        CNVCaller cn(ctx);
-                        cn.sample_size = P.sample_size; cn.min_cnv_length = P.min_cnv_length; cn.host_threads = P.host_threads;
-                        cn.runSplitReadCopyNumberPredictionsAll(sj, hmm);
-                        early.pre_ready = true;
-                        csvhost::set_thread_context(nullptr);
+                        early.pre_ready = taken_b >= n_lane_contigs;
                     } catch (...) { early.err = std::current_exception(); csvhost::set_thread_context(nullptr); }
                 };
                 const bool can_split_only = !P.save_cnv && !forced_batches && !env_on("CSV_NO_SPLIT_BESIDE_PASS");
@@ -870,7 +881,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
             std::function<void(size_t, size_t)> note;
             if (early_cn) note = [&early](size_t l, size_t k) { std::lock_guard<std::mutex> g(early.mu); early.merged.emplace_back(l, k); };
             std::function<void(size_t, size_t)> dev_note;
-            if (split_task) dev_note = [&early](size_t, size_t) { std::lock_guard<std::mutex> g(early.mu); early.device_done++; };
+            if (split_task) dev_note = [&early](size_t l, size_t k) { std::lock_guard<std::mutex> g(early.mu); early.device_done.emplace_back(l, k); };
             processResidentLanes(lanes, nullptr, P.dbscan_epsilon, P.dbscan_min_pts_pct, lane_calls, lane_stats, note, min_mapq, min_oplen, dev_note);
         }
         T.ms_cigar = now_ms() - t_begin;
