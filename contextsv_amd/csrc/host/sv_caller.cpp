@@ -711,10 +711,12 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                             std::vector<size_t> blocks;
                             std::unordered_map<std::string, std::pair<size_t, size_t>> lane_of;
                             for (const auto &lk : snap) {
+                                if (early.finished[which[lk.first][lk.second]]) continue;      // (went through an early batch: its split calls are merged in)
                                 const int b = S->block_of[which[lk.first][lk.second]];
                                 if (b >= 0) blocks.push_back((size_t)b);
                                 lane_of[contigs[which[lk.first][lk.second]].name] = lk;
                             }
+                            if (blocks.empty()) { csvhost::set_thread_context(nullptr); continue; }
                             std::unordered_map<std::string, std::vector<SVCall>> part;
                             S->pass->finishFor(blocks, part);
                             std::vector<CNVCaller::ContigJob> sj;
@@ -776,7 +778,7 @@ void SVCaller::runResident(const std::vector<ResidentContig> &contigs_in, const 
                         // (CSV_EARLY_SMALL_BATCHES: tests — a batch whenever three more contigs are merged, down to the last one)
                         const bool small_batches = env_on("CSV_EARLY_SMALL_BATCHES");
                         if (unmerged < 8 && !env_on("CSV_EARLY_CN_WAIT_ALL") && !small_batches) {
-                            if (taken == 0 && can_split_only) {                         // no batch of this kind at all: the split chain alone, for every contig
+                            if (can_split_only) {                                       // no (more) batches of this kind: the split chain alone, for every contig that went through none
                                 bool go = false;
                                 { std::lock_guard<std::mutex> l(early.mu); if (!early.pass_over) { early.split_only = true; go = true; } }
                                 if (go) split_only_batch();
