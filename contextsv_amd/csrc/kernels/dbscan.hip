@@ -531,12 +531,127 @@ __global__ __launch_bounds__(IVS_THREADS) void dbscan_iv_small_kernel(const uint
     }
 }
 
+// The same labels without the n^2: two intervals can only be neighbours when they share a position, so with the set's points in start
+// order (a bitonic sort of (start, index) pairs in LDS: 66 steps for 2 048 points) the neighbours of p behind it in that order are a
+// stretch that ends at the first start at or beyond p's end. Every neighbour PAIR is met once, from its earlier member, three times over:
+// counts (LDS atomicAdd on both ends), union of core pairs, and the border rule as LDS atomicMax / atomicMin on the non-core end — all
+// results live in ORIGINAL-index space (roots = smallest original index, cluster ids = rank of the root in index order), so the order-free
+// labelling is the brute-force kernel's bit for bit. A genome's final merge: 2 400 calls of one type on chr1 -> 5.8e6 pair tests per phase
+// on one workgroup (350 us, the whole launch waits for it) against a few thousand.
+__global__ __launch_bounds__(IVS_THREADS) void dbscan_iv_small_sorted_kernel(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end,
+                                                                            const uint64_t *__restrict__ seg_off, uint64_t n_seg, double eps, int min_pts,
+                                                                            int32_t *__restrict__ labels)
+{
+    __shared__ uint32_t ss[IVS_MAX], se[IVS_MAX], oi[IVS_MAX];          // start order: start (sign-biased while sorting), end, original index
+    __shared__ uint32_t lpar[IVS_MAX], lcid[IVS_MAX + 1];               // original-index space
+    __shared__ int32_t acc[IVS_MAX], bmin[IVS_MAX];                     // neighbour count, then the border rule's maximum start-point id; its minimum core id
+    __shared__ uint8_t lcore[IVS_MAX];
+    __shared__ uint32_t wave_tot[IVS_THREADS / WAVE];
+    for (uint64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const uint64_t o0 = seg_off[seg];
+        const uint64_t n64 = seg_off[seg + 1] - o0;
+        if (n64 == 0 || n64 > (uint64_t)IVS_MAX) continue;           // larger sets: the windowed path (host decides)
+        const int n = (int)n64;
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        __syncthreads();
+        // (start, index) pairs in the order of (int)start — the predicate compares as int (sv_object / dbscan.cpp work in int) —, padded with +inf
+        for (int i = threadIdx.x; i < np2; i += IVS_THREADS) {
+            ss[i] = i < n ? (start[o0 + i] ^ 0x80000000u) : 0xffffffffu;
+            oi[i] = (uint32_t)i;
+            if (i < n) { lpar[i] = (uint32_t)i; acc[i] = 0; bmin[i] = INT32_MAX; }
+        }
+        __syncthreads();
+        for (int k = 2; k <= np2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < np2 / 2; t += IVS_THREADS) {
+                    const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const uint32_t a = ss[lo], b = ss[hi], ia = oi[lo], ib = oi[hi];
+                    const bool gt = a > b || (a == b && ia > ib);                  // (ties by index: a definite order, nothing depends on it)
+                    if (gt == up) { ss[lo] = b; ss[hi] = a; oi[lo] = ib; oi[hi] = ia; }
+                }
+                __syncthreads();
+            }
+        for (int p = threadIdx.x; p < n; p += IVS_THREADS) { ss[p] ^= 0x80000000u; se[p] = end[o0 + oi[p]]; }
+        __syncthreads();
+        // ---- neighbour counts: |N(i)| includes i itself (regionQuery, dbscan.cpp:59-67)
+        for (int p = threadIdx.x; p < n; p += IVS_THREADS) {
+            const uint32_t sp = ss[p], ep = se[p];
+            int c = ivs_nb(sp, ep, sp, ep, eps) ? 1 : 0;
+            for (int q = p + 1; q < n && (int)ss[q] < (int)ep; q++)
+                if (ivs_nb(sp, ep, ss[q], se[q], eps)) { c++; atomicAdd(&acc[oi[q]], 1); }
+            atomicAdd(&acc[oi[p]], c);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += IVS_THREADS) lcore[i] = acc[i] >= min_pts;
+        __syncthreads();
+        // ---- components of the core points (larger root under smaller: a component's root is its smallest original index)
+        for (int p = threadIdx.x; p < n; p += IVS_THREADS) {
+            acc[oi[p]] = -1;                                             // (from here on: the border rule's maximum)
+            if (!lcore[oi[p]]) continue;
+            const uint32_t sp = ss[p], ep = se[p];
+            for (int q = p + 1; q < n && (int)ss[q] < (int)ep; q++) {
+                if (!lcore[oi[q]] || !ivs_nb(sp, ep, ss[q], se[q], eps)) continue;
+                uint32_t a = oi[p], b = oi[q];
+                for (;;) {
+                    a = lds_find(lpar, a); b = lds_find(lpar, b);
+                    if (a == b) break;
+                    if (a > b) { const uint32_t t = a; a = b; b = t; }
+                    if (atomicCAS(&lpar[b], b, a) == b) break;
+                }
+            }
+        }
+        __syncthreads();
+        // start points (roots) ranked in index order: exclusive prefix sum of the root flags
+        uint32_t carry = 0;
+        for (int i0 = 0; i0 < n; i0 += IVS_THREADS) {
+            const int i = i0 + (int)threadIdx.x;
+            const uint32_t v = (i < n && lcore[i] && lds_ld(&lpar[i]) == (uint32_t)i) ? 1u : 0u;
+            const uint32_t incl = wave_incl_sum(v);
+            if (lane_id() == 63) wave_tot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t before = carry;
+            for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wave_tot[w];
+            if (i < n) lcid[i] = before + incl - v;
+            uint32_t tot = 0;
+            for (int w = 0; w < IVS_THREADS / WAVE; w++) tot += wave_tot[w];
+            carry += tot;
+            __syncthreads();
+        }
+        // ---- border rule: a non-core point takes the largest id among its neighbouring start points, else the smallest among its neighbouring cores
+        for (int p = threadIdx.x; p < n; p += IVS_THREADS) {
+            const uint32_t sp = ss[p], ep = se[p], a = oi[p];
+            const bool ca = lcore[a];
+            for (int q = p + 1; q < n && (int)ss[q] < (int)ep; q++) {
+                const uint32_t b = oi[q];
+                const bool cb = lcore[b];
+                if (ca == cb || !ivs_nb(sp, ep, ss[q], se[q], eps)) continue;
+                const uint32_t core = ca ? a : b, other = ca ? b : a;
+                const uint32_t r = lds_find(lpar, core);
+                const int32_t c = (int32_t)lcid[r];
+                if (r == core) atomicMax(&acc[other], c); else atomicMin(&bmin[other], c);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += IVS_THREADS) {
+            int32_t lab;
+            if (lcore[i]) lab = (int32_t)lcid[lds_find(lpar, (uint32_t)i)];
+            else lab = acc[i] >= 0 ? acc[i] : (bmin[i] != INT32_MAX ? bmin[i] : -2);
+            labels[o0 + i] = lab;
+        }
+    }
+}
+
 void launch_dbscan_iv_small_batched(hipStream_t s, const uint32_t *start, const uint32_t *end, const uint64_t *seg_off, uint64_t n_seg, double eps,
                                     int min_pts, int32_t *labels)
 {
     if (n_seg == 0) return;
     const unsigned grid = (unsigned)std::min<uint64_t>(n_seg, 8192);
-    hipLaunchKernelGGL(dbscan_iv_small_kernel, dim3(grid), dim3(IVS_THREADS), 0, s, start, end, seg_off, n_seg, eps, min_pts, labels);
+    const char *be = getenv("CSV_DBSCAN_SMALL_BRUTE");                         // (A/B, tests: all pairs)
+    const bool brute = be && *be && *be != '0';
+    if (brute) hipLaunchKernelGGL(dbscan_iv_small_kernel, dim3(grid), dim3(IVS_THREADS), 0, s, start, end, seg_off, n_seg, eps, min_pts, labels);
+    else hipLaunchKernelGGL(dbscan_iv_small_sorted_kernel, dim3(grid), dim3(IVS_THREADS), 0, s, start, end, seg_off, n_seg, eps, min_pts, labels);
 }
 
 }  // namespace csv
