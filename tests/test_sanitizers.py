@@ -1,6 +1,7 @@
 """The committed sanitizer / fuzz recipes of the host code ("ASan/UBSan build of host code"; CPU only — the GPU pool takes no
 sanitizer runs). `make -C contextsv_amd/csrc asan tsan` builds:
   _obj/fuzz_io_asan               tools/fuzz/fuzz_io.cpp: DEFLATE / BAM / VCF mutation fuzzers under AddressSanitizer + UBSan
+  _obj/fuzz_sort_select_asan      tools/fuzz/fuzz_sort_select.cpp: sort_select.h against std::sort on random inputs
   _obj/libcontextsv_host_asan.so  the whole host mirror under the same sanitizers
   _obj/tsan_pool                  tools/fuzz/tsan_pool.cpp: the thread pools and the threaded BGZF reader / writer under ThreadSanitizer
 Each gets a short run here (a few hundred inputs per fuzzer; `fuzz_io_asan <mode> <iterations> <seed>` runs longer ones by hand), and the
@@ -37,6 +38,10 @@ def _run(cmd, env=None, timeout=300):
 def test_fuzz_drivers_under_asan(built, mode, iters):
     out = _run([os.path.join(built, "fuzz_io_asan"), mode, str(iters), "20261005"])
     assert out.startswith(mode + ":")
+
+
+def test_sort_select_against_std_sort_under_asan(built):
+    assert "cases equal to std::sort" in _run([os.path.join(built, "fuzz_sort_select_asan"), "400", "20261005"])
 
 
 def test_thread_pools_under_tsan(built):
