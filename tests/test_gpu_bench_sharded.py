@@ -61,3 +61,15 @@ def test_gather_on_the_gpu_stages_through_pinned_buffers():
     once another copy of the HIP runtime (the product library's) is up in the process."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gather_device_check.py")], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "gather ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("tech,depth", [("ont", "30"), ("hifi", "60")])
+def test_repeated_steps_give_one_call_set(tech, depth):
+    """tools/soak_digest.py on a scaled-down genome: 24 contigs, three lanes, 40 steps — the early batches, the split chain's portions beside the
+    pass and the radix passes' look-back depend on timing; the SHA-256 of every step's call records must be one value (at full scale: 150
+    steps each, profiles/r03e/soak.txt)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_digest.py"), "--tech", tech, "--depth", depth, "--scale", "0.004", "--steps", "40"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["distinct_digests"] == 1 and j["steps"] == 40 and j["calls"] > 20
